@@ -1,0 +1,344 @@
+// Device-side CSR construction: COO -> CSR, exact transpose, and key-list -> CSR
+// for the synthetic graphs.  Ordering is done with one stable LSD radix sort of
+// 64-bit (major << 32 | minor) keys (rocPRIM); everything around it is plain
+// HIP.  No arithmetic touches the values except the final fp64 -> fp32 cast.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "gcnx_common.h"
+
+namespace gcnx {
+
+__global__ void coo_keys_kernel(int64_t nnz, int64_t n_rows, int64_t n_cols,
+                                const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                int64_t stride, uint64_t *__restrict__ keys,
+                                int64_t *__restrict__ idx, int *__restrict__ bad) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const int32_t r = row[k * stride];
+  const int32_t c = col[k * stride];
+  if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) {
+    atomicOr(bad, 1);
+    keys[k] = 0;
+  } else {
+    keys[k] = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+  }
+  idx[k] = k;
+}
+
+// row of slot s = last r with row_ptr[r] <= s
+__device__ __forceinline__ int64_t row_of_slot(const int64_t *row_ptr, int64_t n_rows, int64_t s) {
+  int64_t lo = 0, hi = n_rows;
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] <= s) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void transpose_keys_kernel(int64_t nnz, int64_t n_rows,
+                                      const int64_t *__restrict__ row_ptr,
+                                      const int32_t *__restrict__ col_idx,
+                                      uint64_t *__restrict__ keys, int64_t *__restrict__ idx) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const int64_t r = row_of_slot(row_ptr, n_rows, s);
+  keys[s] = ((uint64_t)(uint32_t)col_idx[s] << 32) | (uint32_t)r;
+  idx[s] = s;
+}
+
+// After sorting: minor index, permuted value (cast last) and permutation.
+__global__ void csr_fill_kernel(int64_t nnz, const uint64_t *__restrict__ keys,
+                                const int64_t *__restrict__ idx, const void *__restrict__ val,
+                                int val_is_f64, int32_t *__restrict__ col_idx,
+                                float *__restrict__ val_out, int64_t *__restrict__ perm) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const int64_t k = idx[s];
+  col_idx[s] = (int32_t)(uint32_t)(keys[s] & 0xffffffffull);
+  if (val) {
+    val_out[s] = val_is_f64 ? (float)static_cast<const double *>(val)[k]
+                            : static_cast<const float *>(val)[k];
+  }
+  if (perm) perm[s] = k;
+}
+
+// row_ptr[r] = number of sorted keys whose major index is < r (+ base row).
+__global__ void row_ptr_kernel(int64_t n_rows, int64_t row_base, int64_t nnz,
+                               const uint64_t *__restrict__ keys, int64_t *__restrict__ row_ptr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_rows) return;
+  const uint64_t target = (uint64_t)(r + row_base) << 32;
+  int64_t lo = 0, hi = nnz;  // first position with key >= target
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  row_ptr[r] = lo;
+}
+
+static int bits_for(int64_t n) {
+  int b = 1;
+  while (b < 63 && (1ll << b) < n) ++b;
+  return b;
+}
+
+static size_t sort_pairs_temp_bytes(int64_t n, int end_bit) {
+  size_t bytes = 0;
+  uint64_t *k = nullptr;
+  int64_t *v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0u, (unsigned)end_bit,
+                                  (hipStream_t)0);
+  return bytes;
+}
+
+static size_t sort_keys_temp_bytes(int64_t n, int end_bit) {
+  size_t bytes = 0;
+  uint64_t *k = nullptr;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, k, k, (size_t)n, 0u, (unsigned)end_bit,
+                                 (hipStream_t)0);
+  return bytes;
+}
+
+struct PairLayout {
+  size_t keys_in, keys_out, idx_in, idx_out, flag, temp, temp_bytes, total;
+};
+
+static PairLayout pair_layout(int64_t nnz, int end_bit) {
+  PairLayout l;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  size_t off = 0;
+  l.keys_in = off;  off += align_up(n * 8, 256);
+  l.keys_out = off; off += align_up(n * 8, 256);
+  l.idx_in = off;   off += align_up(n * 8, 256);
+  l.idx_out = off;  off += align_up(n * 8, 256);
+  l.flag = off;     off += 256;
+  l.temp = off;
+  l.temp_bytes = nnz > 0 ? sort_pairs_temp_bytes(nnz, end_bit) : 0;
+  off += align_up(l.temp_bytes, 256);
+  l.total = off;
+  return l;
+}
+
+// keys/idx -> sorted -> (row_ptr, col_idx, val, perm)
+static int finish_from_pairs(const PairLayout &l, char *ws, int64_t n_major, int64_t nnz,
+                             int end_bit, const void *val, int val_is_f64, int64_t *row_ptr,
+                             int32_t *col_idx, float *val_out, int64_t *perm, hipStream_t st) {
+  uint64_t *keys_in = reinterpret_cast<uint64_t *>(ws + l.keys_in);
+  uint64_t *keys_out = reinterpret_cast<uint64_t *>(ws + l.keys_out);
+  int64_t *idx_in = reinterpret_cast<int64_t *>(ws + l.idx_in);
+  int64_t *idx_out = reinterpret_cast<int64_t *>(ws + l.idx_out);
+  if (nnz > 0) {
+    size_t tb = l.temp_bytes;
+    GCNX_CHECK_HIP(rocprim::radix_sort_pairs(ws + l.temp, tb, keys_in, keys_out, idx_in, idx_out,
+                                             (size_t)nnz, 0u, (unsigned)end_bit, st));
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, nnz,
+                       keys_out, idx_out, val, val_is_f64, col_idx, val_out, perm);
+    GCNX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(row_ptr_kernel, dim3((unsigned)ceil_div(n_major + 1, 256)), dim3(256), 0, st,
+                     n_major, (int64_t)0, nnz, keys_out, row_ptr);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+// ---- key list -> CSR (synthetic graphs) -----------------------------------
+
+__global__ void append_diag_kernel(int64_t row_begin, int64_t n_local, uint64_t *__restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_local) return;
+  const uint64_t r = (uint64_t)(row_begin + i);
+  keys[i] = (r << 32) | r;
+}
+
+__global__ void unique_flag_kernel(int64_t n, const uint64_t *__restrict__ keys,
+                                   int64_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ void unique_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys,
+                                      const int64_t *__restrict__ pos,
+                                      uint64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0 || keys[i] != keys[i - 1]) out[pos[i]] = keys[i];
+}
+
+__global__ void keys_to_csr_kernel(int64_t n, const uint64_t *__restrict__ keys,
+                                   int32_t *__restrict__ col_idx, float *__restrict__ val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  col_idx[i] = (int32_t)(uint32_t)(keys[i] & 0xffffffffull);
+  val[i] = 1.0f;
+}
+
+struct KeyLayout {
+  size_t keys_sorted, pos, count, temp, temp_bytes, total;
+};
+
+static KeyLayout key_layout(int64_t n_keys) {
+  KeyLayout l;
+  const size_t n = (size_t)(n_keys > 0 ? n_keys : 1);
+  size_t off = 0;
+  l.keys_sorted = off; off += align_up(n * 8, 256);
+  l.pos = off;         off += align_up(n * 8, 256);
+  l.count = off;       off += 256;
+  l.temp = off;
+  size_t t1 = n_keys > 0 ? sort_keys_temp_bytes(n_keys, 64) : 0;
+  size_t t2 = 0;
+  int64_t *p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, t2, p, p, (int64_t)0, n, rocprim::plus<int64_t>(),
+                                (hipStream_t)0);
+  l.temp_bytes = t1 > t2 ? t1 : t2;
+  off += align_up(l.temp_bytes, 256);
+  l.total = off;
+  return l;
+}
+
+}  // namespace gcnx
+
+using namespace gcnx;
+
+extern "C" size_t gcnx_csr_from_coo_workspace_bytes(int64_t n_rows, int64_t nnz) {
+  if (n_rows < 0 || nnz < 0) return 0;
+  return pair_layout(nnz, 32 + bits_for(n_rows)).total;
+}
+
+extern "C" int gcnx_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *row,
+                                 const int32_t *col, int64_t coord_stride, const void *val,
+                                 int val_is_f64, int64_t *row_ptr, int32_t *col_idx,
+                                 float *val_out, int64_t *perm_out, void *ws, size_t ws_bytes,
+                                 void *stream) {
+  GCNX_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && coord_stride >= 1, GCNX_ERR_INVALID_ARG,
+               "csr_from_coo: bad size");
+  GCNX_REQUIRE(n_rows < INT32_MAX && n_cols < INT32_MAX, GCNX_ERR_UNSUPPORTED,
+               "csr_from_coo: more than 2^31-1 rows or columns");
+  GCNX_REQUIRE(row_ptr, GCNX_ERR_INVALID_ARG, "csr_from_coo: null row_ptr");
+  GCNX_REQUIRE(nnz == 0 || (row && col && val && col_idx && val_out), GCNX_ERR_INVALID_ARG,
+               "csr_from_coo: null array");
+  const int end_bit = 32 + bits_for(n_rows);
+  const PairLayout l = pair_layout(nnz, end_bit);
+  GCNX_REQUIRE(ws && ws_bytes >= l.total, GCNX_ERR_WORKSPACE,
+               "csr_from_coo: workspace of %zu bytes required, got %zu", l.total, ws_bytes);
+  hipStream_t st = as_stream(stream);
+  char *w = static_cast<char *>(ws);
+  int *bad = reinterpret_cast<int *>(w + l.flag);
+  GCNX_CHECK_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(coo_keys_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, nnz,
+                       n_rows, n_cols, row, col, coord_stride,
+                       reinterpret_cast<uint64_t *>(w + l.keys_in),
+                       reinterpret_cast<int64_t *>(w + l.idx_in), bad);
+    GCNX_CHECK_LAUNCH();
+  }
+  int h_bad = 0;
+  GCNX_CHECK_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  GCNX_REQUIRE(h_bad == 0, GCNX_ERR_INDEX_RANGE,
+               "csr_from_coo: a coordinate lies outside %lld x %lld", (long long)n_rows,
+               (long long)n_cols);
+  int rc = finish_from_pairs(l, w, n_rows, nnz, end_bit, val, val_is_f64, row_ptr, col_idx,
+                             val_out, perm_out, st);
+  if (rc != GCNX_OK) return rc;
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  return GCNX_OK;
+}
+
+extern "C" size_t gcnx_csr_transpose_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  if (n_rows < 0 || n_cols < 0 || nnz < 0) return 0;
+  return pair_layout(nnz, 32 + bits_for(n_cols)).total;
+}
+
+extern "C" int gcnx_csr_transpose(const gcnx_csr *a, int64_t *t_row_ptr, int32_t *t_col_idx,
+                                  float *t_val, int64_t *perm_out, void *ws, size_t ws_bytes,
+                                  void *stream) {
+  GCNX_REQUIRE(a && t_row_ptr, GCNX_ERR_INVALID_ARG, "csr_transpose: null argument");
+  GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0, GCNX_ERR_INVALID_ARG,
+               "csr_transpose: bad size");
+  GCNX_REQUIRE(a->n_rows < INT32_MAX && a->n_cols < INT32_MAX, GCNX_ERR_UNSUPPORTED,
+               "csr_transpose: more than 2^31-1 rows or columns");
+  GCNX_REQUIRE(a->nnz == 0 || (a->row_ptr && a->col_idx && a->val && t_col_idx && t_val),
+               GCNX_ERR_INVALID_ARG, "csr_transpose: null array");
+  const int end_bit = 32 + bits_for(a->n_cols);
+  const PairLayout l = pair_layout(a->nnz, end_bit);
+  GCNX_REQUIRE(ws && ws_bytes >= l.total, GCNX_ERR_WORKSPACE,
+               "csr_transpose: workspace of %zu bytes required, got %zu", l.total, ws_bytes);
+  hipStream_t st = as_stream(stream);
+  char *w = static_cast<char *>(ws);
+  if (a->nnz > 0) {
+    hipLaunchKernelGGL(transpose_keys_kernel, dim3((unsigned)ceil_div(a->nnz, 256)), dim3(256), 0,
+                       st, a->nnz, a->n_rows, a->row_ptr, a->col_idx,
+                       reinterpret_cast<uint64_t *>(w + l.keys_in),
+                       reinterpret_cast<int64_t *>(w + l.idx_in));
+    GCNX_CHECK_LAUNCH();
+  }
+  int rc = finish_from_pairs(l, w, a->n_cols, a->nnz, end_bit, a->val, 0, t_row_ptr, t_col_idx,
+                             t_val, perm_out, st);
+  if (rc != GCNX_OK) return rc;
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  return GCNX_OK;
+}
+
+extern "C" size_t gcnx_csr_from_keys_workspace_bytes(int64_t n_keys, int64_t n_local_rows) {
+  if (n_keys < 0 || n_local_rows < 0) return 0;
+  return key_layout(n_keys + n_local_rows).total;
+}
+
+extern "C" int gcnx_csr_from_keys(uint64_t *keys, int64_t n_keys, int64_t row_begin,
+                                  int64_t row_end, int add_identity, int64_t *row_ptr,
+                                  int32_t *col_idx, float *val, int64_t *h_nnz, void *ws,
+                                  size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(keys && row_ptr && col_idx && val && h_nnz, GCNX_ERR_INVALID_ARG,
+               "csr_from_keys: null argument");
+  GCNX_REQUIRE(n_keys >= 0 && row_begin >= 0 && row_end >= row_begin && row_end < INT32_MAX,
+               GCNX_ERR_INVALID_ARG, "csr_from_keys: bad size");
+  const int64_t n_local = row_end - row_begin;
+  const int64_t total = n_keys + (add_identity ? n_local : 0);
+  const KeyLayout l = key_layout(n_keys + n_local);
+  GCNX_REQUIRE(ws && ws_bytes >= l.total, GCNX_ERR_WORKSPACE,
+               "csr_from_keys: workspace of %zu bytes required, got %zu", l.total, ws_bytes);
+  hipStream_t st = as_stream(stream);
+  char *w = static_cast<char *>(ws);
+  uint64_t *sorted = reinterpret_cast<uint64_t *>(w + l.keys_sorted);
+  int64_t *pos = reinterpret_cast<int64_t *>(w + l.pos);
+  *h_nnz = 0;
+  if (add_identity && n_local > 0) {
+    // caller reserved n_local extra key slots behind the n_keys edges
+    hipLaunchKernelGGL(append_diag_kernel, dim3((unsigned)ceil_div(n_local, 256)), dim3(256), 0, st,
+                       row_begin, n_local, keys + n_keys);
+    GCNX_CHECK_LAUNCH();
+  }
+  int64_t n_unique = 0;
+  if (total > 0) {
+    size_t tb = l.temp_bytes;
+    GCNX_CHECK_HIP(rocprim::radix_sort_keys(w + l.temp, tb, keys, sorted, (size_t)total, 0u, 64u, st));
+    const unsigned g = (unsigned)ceil_div(total, 256);
+    hipLaunchKernelGGL(unique_flag_kernel, dim3(g), dim3(256), 0, st, total, sorted, pos);
+    GCNX_CHECK_LAUNCH();
+    // last flag + last exclusive position = number of unique keys
+    int64_t last_flag = 0, last_pos = 0;
+    GCNX_CHECK_HIP(hipMemcpyAsync(&last_flag, pos + total - 1, 8, hipMemcpyDeviceToHost, st));
+    tb = l.temp_bytes;
+    GCNX_CHECK_HIP(rocprim::exclusive_scan(w + l.temp, tb, pos, pos, (int64_t)0, (size_t)total,
+                                           rocprim::plus<int64_t>(), st));
+    GCNX_CHECK_HIP(hipMemcpyAsync(&last_pos, pos + total - 1, 8, hipMemcpyDeviceToHost, st));
+    // unique keys go back into the caller's key buffer (it is scratch by now)
+    hipLaunchKernelGGL(unique_scatter_kernel, dim3(g), dim3(256), 0, st, total, sorted, pos, keys);
+    GCNX_CHECK_LAUNCH();
+    GCNX_CHECK_HIP(hipStreamSynchronize(st));
+    n_unique = last_pos + last_flag;
+    hipLaunchKernelGGL(keys_to_csr_kernel, dim3((unsigned)ceil_div(n_unique, 256)), dim3(256), 0, st,
+                       n_unique, keys, col_idx, val);
+    GCNX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(row_ptr_kernel, dim3((unsigned)ceil_div(n_local + 1, 256)), dim3(256), 0, st,
+                     n_local, row_begin, n_unique, keys, row_ptr);
+  GCNX_CHECK_LAUNCH();
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  *h_nnz = n_unique;
+  return GCNX_OK;
+}

@@ -1,0 +1,274 @@
+// Dense fp32 product  C = act(alpha * op(A) * op(B) + beta * C)  for gfx950.
+//
+// Two kernels behind one entry point, chosen by shape (they never serve the
+// same shape):
+//   * gemm_mfma_kernel   -- tall products with K and N multiples of 32 and at
+//     least 64 wide (hidden >= 64): v_mfma_f32_32x32x2_f32, exact fp32
+//     (a k-ordered fmaf chain), operands staged through LDS.
+//   * gemm_tile_kernel   -- everything else (hidden < 64, the class dimension,
+//     transposed operands): a 64x64x16 register-tiled VALU kernel.
+// A product whose reduction dimension dwarfs its output (the weight gradient
+// H^T * dP, reduced over all nodes) is split along K across workgroups; each
+// split writes its tile to the workspace and gemm_reduce_kernel adds the tiles
+// in split order, so the sum is reproducible.
+#include "gcnx_common.h"
+
+namespace gcnx {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+struct GemmArgs {
+  int64_t M, N, K;
+  const float *A;
+  int64_t lda;
+  const float *B;
+  int64_t ldb;
+  float *C;
+  int64_t ldc;
+  float alpha, beta;
+  int relu;
+  float *partial;  // [splits][M][N] when splits > 1
+  int64_t k_per_split;
+  int splits;
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(kBlock) void gemm_tile_kernel(const GemmArgs g) {
+  __shared__ float As[TK][TM + 4];
+  __shared__ float Bs[TK][TN + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * TM, n0 = (int64_t)blockIdx.y * TN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+  for (int64_t kk = kbeg; kk < kend; kk += TK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * kBlock;
+      int m, k;
+      if (!TA) { m = e >> 4; k = e & 15; } else { k = e >> 6; m = e & 63; }
+      const int64_t gm = m0 + m, gk = kk + k;
+      float v = 0.0f;
+      if (gm < g.M && gk < kend) v = TA ? g.A[gk * g.lda + gm] : g.A[gm * g.lda + gk];
+      As[k][m] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * kBlock;
+      int n, k;
+      if (!TB) { k = e >> 6; n = e & 63; } else { n = e >> 4; k = e & 15; }
+      const int64_t gn = n0 + n, gk = kk + k;
+      float v = 0.0f;
+      if (gn < g.N && gk < kend) v = TB ? g.B[gn * g.ldb + gk] : g.B[gk * g.ldb + gn];
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t gm = m0 + ty * 4 + i;
+    if (gm >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gn = n0 + tx * 4 + j;
+      if (gn >= g.N) continue;
+      if (g.splits > 1) {
+        g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[i][j];
+      } else {
+        float *dst = g.C + gm * g.ldc + gn;
+        float out = g.alpha * acc[i][j];
+        if (g.beta != 0.0f) out += g.beta * *dst;
+        if (g.relu) out = fmaxf(out, 0.0f);
+        *dst = out;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gemm_reduce_kernel(const GemmArgs g) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.M * g.N) return;
+  float s = 0.0f;
+  for (int z = 0; z < g.splits; ++z) s += g.partial[(int64_t)z * g.M * g.N + e];
+  float *dst = g.C + (e / g.N) * g.ldc + (e % g.N);
+  float out = g.alpha * s;
+  if (g.beta != 0.0f) out += g.beta * *dst;
+  if (g.relu) out = fmaxf(out, 0.0f);
+  *dst = out;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA kernel:  C[M,N] = A[M,K] * B[K,N]  (no transposes), N % 32 == 0,
+// K % 16 == 0.  Workgroup = 4 wavefronts, block tile 128 x BN (BN = 128);
+// wavefront w owns rows [32w, 32w+32) of the block tile and all BN columns:
+// BN/32 accumulator tiles of 32x32 (16 registers each).  Per K-step of 16 the
+// block stages A[128x16] and B[16xBN] in LDS; one v_mfma_f32_32x32x2_f32 takes
+// A[i=lane&31][k=lane>>5] and B[k=lane>>5][j=lane&31] as one float each.
+// ---------------------------------------------------------------------------
+typedef float __attribute__((ext_vector_type(16))) f16v;
+typedef float __attribute__((ext_vector_type(4))) f4v;
+
+constexpr int MB = 128, NB = 128, KB = 16;
+
+__global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
+  // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
+  // stride-17 words (conflict free), lanes 32..63 the next k.
+  __shared__ float As[MB * (KB + 1)];
+  __shared__ float Bs[KB * NB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * MB;
+  const int64_t n0 = (int64_t)blockIdx.y * NB;
+  f16v acc[NB / 32];
+#pragma unroll
+  for (int t = 0; t < NB / 32; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  const int li = lane & 31, lk = lane >> 5;
+  for (int64_t kk = 0; kk < g.K; kk += KB) {
+    // A: 128 rows x 16 floats = 512 float4, two per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int m = e >> 2, q = e & 3;
+      const int64_t gm = m0 + m;
+      f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (gm < g.M) v = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
+      float *d = As + m * (KB + 1) + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    // B: 16 rows x 128 floats = 512 float4, two per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      const f4v v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+      *reinterpret_cast<f4v *>(Bs + k * NB + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < KB; k2 += 2) {
+      const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
+#pragma unroll
+      for (int t = 0; t < NB / 32; ++t) {
+        const float b = Bs[(k2 + lk) * NB + t * 32 + li];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int t = 0; t < NB / 32; ++t) {
+#pragma unroll
+    for (int rgi = 0; rgi < 16; ++rgi) {
+      const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
+      const int64_t gm = m0 + w * 32 + row;
+      if (gm >= g.M) continue;
+      float *dst = g.C + gm * g.ldc + n0 + t * 32 + li;
+      float out = g.alpha * acc[t][rgi];
+      if (g.beta != 0.0f) out += g.beta * *dst;
+      if (g.relu) out = fmaxf(out, 0.0f);
+      *dst = out;
+    }
+  }
+}
+
+static int choose_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ceil_div(M, TM) * ceil_div(N, TN);
+  if (tiles >= 1024 || K <= 4096) return 1;
+  int64_t s = 2048 / tiles;
+  const int64_t max_s = ceil_div(K, 2048);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace gcnx
+
+using namespace gcnx;
+
+extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N,
+                                            int64_t K) {
+  (void)trans_a; (void)trans_b;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s = choose_splits(M, N, K);
+  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                             const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                             int64_t ldc, float alpha, float beta, int fuse_relu, void *ws,
+                             size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
+  if (M == 0 || N == 0) return GCNX_OK;
+  GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
+  GCNX_REQUIRE(K == 0 || (A && B), GCNX_ERR_INVALID_ARG, "gemm: null operand");
+  GCNX_REQUIRE(K == 0 || (lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N)),
+               GCNX_ERR_INVALID_ARG, "gemm: leading dimension too small");
+  hipStream_t st = as_stream(stream);
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta; g.relu = fuse_relu;
+  g.partial = nullptr; g.splits = 1; g.k_per_split = K > 0 ? K : 1;
+
+  const bool mfma_ok = !trans_a && !trans_b && N >= 64 && K >= 64 && (N % NB == 0) &&
+                       (K % KB == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) &&
+                       aligned16(B) && M >= 4 * MB;
+  if (mfma_ok) {
+    // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
+    const int64_t mt = ceil_div(M, MB);
+    GCNX_REQUIRE(mt <= 0x7fffffffll && N / NB <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
+    hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)mt, (unsigned)(N / NB)), dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+
+  const int splits = choose_splits(M, N, K);
+  if (splits > 1) {
+    const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+    GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
+                 "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
+    g.partial = static_cast<float *>(ws);
+    g.splits = splits;
+    g.k_per_split = ceil_div(ceil_div(K, splits), TK) * TK;
+  }
+  GCNX_REQUIRE(ceil_div(M, TM) <= 0x7fffffffll && ceil_div(N, TN) <= 65535, GCNX_ERR_UNSUPPORTED,
+               "gemm: shape too large");
+  const dim3 grid((unsigned)ceil_div(M, TM), (unsigned)ceil_div(N, TN), (unsigned)g.splits);
+  if (!trans_a && !trans_b) hipLaunchKernelGGL((gemm_tile_kernel<false, false>), grid, dim3(kBlock), 0, st, g);
+  else if (!trans_a && trans_b) hipLaunchKernelGGL((gemm_tile_kernel<false, true>), grid, dim3(kBlock), 0, st, g);
+  else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_tile_kernel<true, false>), grid, dim3(kBlock), 0, st, g);
+  else hipLaunchKernelGGL((gemm_tile_kernel<true, true>), grid, dim3(kBlock), 0, st, g);
+  GCNX_CHECK_LAUNCH();
+  if (g.splits > 1) {
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+  }
+  return GCNX_OK;
+}

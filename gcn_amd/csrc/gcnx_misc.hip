@@ -1,0 +1,380 @@
+// Glue kernels of one training step: masked softmax cross-entropy (+accuracy,
+// +gradient), dense dropout, relu/dropout backward, Adam, Bernoulli masks,
+// degree normalisation, support interleaving.  All are streaming or tiny; the
+// reductions are two-level with a fixed order (no float atomics), so results are
+// reproducible run to run.
+#include "gcnx_common.h"
+#include "gcnx_philox.h"
+
+namespace gcnx {
+
+typedef float __attribute__((ext_vector_type(4))) f4;
+typedef unsigned char __attribute__((ext_vector_type(4))) u8x4;
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum of `v` over the block; valid in thread 0.  `sh` has kWavesPerBlock slots.
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+// ws layout (doubles): [0] = sum(mask); [1..nb] count partials; then loss
+// partials [nb], hit partials [nb].
+__global__ __launch_bounds__(kBlock) void xent_count_kernel(int64_t n, const uint8_t *__restrict__ mask,
+                                                           double *__restrict__ part) {
+  __shared__ double sh[kWavesPerBlock];
+  double c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    c += mask[i] ? 1.0 : 0.0;
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(kBlock) void final_sum_kernel(int nb, const double *__restrict__ part,
+                                                          double *__restrict__ out) {
+  __shared__ double sh[kWavesPerBlock];
+  double c = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) c += part[i];
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) *out = c;
+}
+
+__global__ __launch_bounds__(kBlock) void xent_rows_kernel(
+    int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
+    const float *__restrict__ labels, int64_t ldl, const uint8_t *__restrict__ mask,
+    const double *__restrict__ msum_p, float *__restrict__ grad, int64_t ldg,
+    double *__restrict__ loss_part, double *__restrict__ hit_part) {
+  __shared__ double sh[kWavesPerBlock];
+  const double msum = *msum_p;
+  const float wgt = msum > 0.0 ? (float)(1.0 / msum) : 0.0f;
+  double loss = 0.0, hit = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float *z = logits + i * ld;
+    const float *y = labels + i * ldl;
+    const bool on = mask[i] != 0;
+    float zmax = z[0];
+    int az = 0, ay = 0;
+    float ybest = y[0];
+    for (int j = 1; j < nc; ++j) {
+      const float zj = z[j], yj = y[j];
+      if (zj > zmax) { zmax = zj; az = j; }
+      if (yj > ybest) { ybest = yj; ay = j; }
+    }
+    float se = 0.0f, ysum = 0.0f;
+    for (int j = 0; j < nc; ++j) { se += __expf(z[j] - zmax); ysum += y[j]; }
+    const float lse = __logf(se);
+    if (on) {
+      float ce = 0.0f;
+      for (int j = 0; j < nc; ++j) ce -= y[j] * ((z[j] - zmax) - lse);
+      loss += (double)ce;
+      hit += (az == ay) ? 1.0 : 0.0;
+    }
+    if (grad) {
+      float *g = grad + i * ldg;
+      const float w = on ? wgt : 0.0f;
+      const float inv = 1.0f / se;
+      for (int j = 0; j < nc; ++j) g[j] = (__expf(z[j] - zmax) * inv * ysum - y[j]) * w;
+    }
+  }
+  loss = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) hit_part[blockIdx.x] = hit;
+}
+
+__global__ __launch_bounds__(kBlock) void xent_final_kernel(int nb, const double *__restrict__ ws_msum,
+                                                           const double *__restrict__ loss_part,
+                                                           const double *__restrict__ hit_part,
+                                                           float *__restrict__ out) {
+  __shared__ double sh[kWavesPerBlock];
+  double l = 0.0, h = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) { l += loss_part[i]; h += hit_part[i]; }
+  l = block_sum(l, sh);
+  h = block_sum(h, sh);
+  if (threadIdx.x == 0) {
+    const double m = *ws_msum;
+    out[0] = m > 0.0 ? (float)(l / m) : 0.0f;
+    out[1] = m > 0.0 ? (float)(h / m) : 0.0f;
+  }
+}
+
+static int xent_blocks(int64_t n) {
+  int64_t b = ceil_div(n, kBlock);
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// ---------------------------------------------------------------- elementwise
+__global__ __launch_bounds__(kBlock) void dropout_dense_kernel(int64_t n, const float *__restrict__ x,
+                                                              const uint8_t *__restrict__ mask,
+                                                              float scale, float *__restrict__ out,
+                                                              int vec_ok) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = vec_ok ? n / 4 : 0;
+  for (int64_t i = tid; i < n4; i += stride) {
+    const f4 v = reinterpret_cast<const f4 *>(x)[i];
+    const u8x4 m = reinterpret_cast<const u8x4 *>(mask)[i];
+    f4 o;
+    o.x = m.x ? v.x * scale : 0.0f;
+    o.y = m.y ? v.y * scale : 0.0f;
+    o.z = m.z ? v.z * scale : 0.0f;
+    o.w = m.w ? v.w * scale : 0.0f;
+    reinterpret_cast<f4 *>(out)[i] = o;
+  }
+  for (int64_t i = n4 * 4 + tid; i < n; i += stride) out[i] = mask[i] ? x[i] * scale : 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(
+    int64_t n, const float *__restrict__ y, const float *__restrict__ dy,
+    const uint8_t *__restrict__ mask, float scale, float *__restrict__ dx, int vec_ok) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = vec_ok ? n / 4 : 0;
+  for (int64_t i = tid; i < n4; i += stride) {
+    const f4 yy = reinterpret_cast<const f4 *>(y)[i];
+    f4 g = reinterpret_cast<const f4 *>(dy)[i];
+    if (mask) {
+      const u8x4 m = reinterpret_cast<const u8x4 *>(mask)[i];
+      g.x = m.x ? g.x * scale : 0.0f;
+      g.y = m.y ? g.y * scale : 0.0f;
+      g.z = m.z ? g.z * scale : 0.0f;
+      g.w = m.w ? g.w * scale : 0.0f;
+    }
+    f4 o;
+    o.x = yy.x > 0.0f ? g.x : 0.0f;
+    o.y = yy.y > 0.0f ? g.y : 0.0f;
+    o.z = yy.z > 0.0f ? g.z : 0.0f;
+    o.w = yy.w > 0.0f ? g.w : 0.0f;
+    reinterpret_cast<f4 *>(dx)[i] = o;
+  }
+  for (int64_t i = n4 * 4 + tid; i < n; i += stride) {
+    float g = dy[i];
+    if (mask) g = mask[i] ? g * scale : 0.0f;
+    dx[i] = y[i] > 0.0f ? g : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float *__restrict__ w,
+                                                     const float *__restrict__ g,
+                                                     float *__restrict__ m, float *__restrict__ v,
+                                                     float lr_t, float b1, float b2, float eps,
+                                                     float wd) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float wi = w[i];
+    const float gi = g[i] + wd * wi;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// byte k of the mask = 1 iff uniform(seed, offset + k) < keep; four consecutive
+// global positions share one Philox block.
+__global__ __launch_bounds__(kBlock) void bernoulli_kernel(int64_t n, float keep, uint64_t seed,
+                                                          uint64_t offset,
+                                                          uint8_t *__restrict__ mask) {
+  const uint64_t first_blk = offset >> 2;
+  const uint64_t last_blk = (offset + (uint64_t)n - 1) >> 2;
+  const uint64_t nblk = last_blk - first_blk + 1;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+       b += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t blk = first_blk + b;
+    const philox4 r = philox4x32_10(blk, 0ull, seed);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t e = blk * 4 + j;
+      if (e >= offset && e < offset + (uint64_t)n) {
+        const float u = (float)(r.v[j] >> 8) * (1.0f / 16777216.0f);
+        mask[e - offset] = u < keep ? 1 : 0;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int64_t row_of_slot2(const int64_t *row_ptr, int64_t n_rows, int64_t s) {
+  int64_t lo = 0, hi = n_rows;
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] <= s) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void normalize_kernel(
+    int64_t nnz, int64_t n_rows, int64_t row_begin, const int64_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col_idx, const float *__restrict__ val,
+    const int32_t *__restrict__ row_sum, const double *__restrict__ d_table, int64_t table_len,
+    float *__restrict__ out, int *__restrict__ bad) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const int64_t r = row_of_slot2(row_ptr, n_rows, s) + row_begin;
+  const int64_t c = col_idx[s];
+  const int64_t kr = row_sum[r], kc = row_sum[c];
+  if (kr < 0 || kr >= table_len || kc < 0 || kc >= table_len) {
+    atomicOr(bad, 1);
+    out[s] = 0.0f;
+    return;
+  }
+  // value at (r,c) of (A.D)^T.D for a symmetric A: fl(fl(a * d[r]) * d[c]);
+  // __dmul_rn keeps the two roundings separate (no contraction).
+  const double t = __dmul_rn((double)val[s], d_table[kr]);
+  out[s] = (float)__dmul_rn(t, d_table[kc]);
+}
+
+__global__ __launch_bounds__(kBlock) void interleave_kernel(
+    int64_t nnz, int32_t n_sup, int32_t i, const int32_t *__restrict__ row,
+    const int32_t *__restrict__ col, int64_t stride, const void *__restrict__ val, int is_f64,
+    int32_t *__restrict__ out_row, int32_t *__restrict__ out_col, void *__restrict__ out_val) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  out_row[k] = row[k * stride];
+  out_col[k] = col[k * stride] * n_sup + i;
+  if (is_f64)
+    static_cast<double *>(out_val)[k] = static_cast<const double *>(val)[k];
+  else
+    static_cast<float *>(out_val)[k] = static_cast<const float *>(val)[k];
+}
+
+static unsigned stream_grid(int64_t n_items) {
+  int64_t b = ceil_div(n_items, kBlock);
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;
+  return (unsigned)b;
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+
+}  // namespace gcnx
+
+using namespace gcnx;
+
+extern "C" size_t gcnx_xent_workspace_bytes(int64_t n) {
+  return (size_t)(1 + 3 * (size_t)xent_blocks(n < 0 ? 0 : n)) * sizeof(double);
+}
+
+extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const float *logits,
+                                            int64_t ld, const float *labels, int64_t ldl,
+                                            const uint8_t *mask, float *out_loss_acc, float *grad,
+                                            int64_t ldg, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(n > 0 && n_class > 0 && logits && labels && mask && out_loss_acc,
+               GCNX_ERR_INVALID_ARG, "xent: bad argument");
+  GCNX_REQUIRE(ld >= n_class && ldl >= n_class && (!grad || ldg >= n_class), GCNX_ERR_INVALID_ARG,
+               "xent: leading dimension smaller than n_class");
+  GCNX_REQUIRE(ws && ws_bytes >= gcnx_xent_workspace_bytes(n), GCNX_ERR_WORKSPACE,
+               "xent: workspace of %zu bytes required", gcnx_xent_workspace_bytes(n));
+  hipStream_t st = as_stream(stream);
+  const int nb = xent_blocks(n);
+  double *w = static_cast<double *>(ws);
+  double *msum = w, *cnt = w + 1, *lp = w + 1 + nb, *hp = w + 1 + 2 * nb;
+  hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(kBlock), 0, st, n, mask, cnt);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, nb, cnt, msum);
+  hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
+                     ldl, mask, msum, grad, ldg, lp, hp);
+  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, lp, hp, out_loss_acc);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_dropout_dense_f32(int64_t n, const float *x, const uint8_t *mask, float scale,
+                                      float *out, void *stream) {
+  GCNX_REQUIRE(n >= 0 && (n == 0 || (x && mask && out)), GCNX_ERR_INVALID_ARG, "dropout: bad argument");
+  if (n == 0) return GCNX_OK;
+  const int vec_ok = aligned16(x) && aligned16(out) && aligned4(mask);
+  hipLaunchKernelGGL(dropout_dense_kernel, dim3(stream_grid(n / 4 + 1)), dim3(kBlock), 0,
+                     as_stream(stream), n, x, mask, scale, out, vec_ok);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_relu_dropout_bwd_f32(int64_t n, const float *y, const float *dy,
+                                         const uint8_t *mask, float scale, float *dx, void *stream) {
+  GCNX_REQUIRE(n >= 0 && (n == 0 || (y && dy && dx)), GCNX_ERR_INVALID_ARG, "relu_bwd: bad argument");
+  if (n == 0) return GCNX_OK;
+  const int vec_ok = aligned16(y) && aligned16(dy) && aligned16(dx) && (!mask || aligned4(mask));
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(stream_grid(n / 4 + 1)), dim3(kBlock), 0,
+                     as_stream(stream), n, y, dy, mask, scale, dx, vec_ok);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_adam_step_f32(int64_t n, float *w, const float *grad, float *m, float *v,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int64_t t, void *stream) {
+  GCNX_REQUIRE(n >= 0 && t >= 1 && (n == 0 || (w && grad && m && v)), GCNX_ERR_INVALID_ARG,
+               "adam: bad argument");
+  if (n == 0) return GCNX_OK;
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) /
+                      (1.0 - pow((double)beta1, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, as_stream(stream), n, w,
+                     grad, m, v, (float)lr_t, beta1, beta2, eps, weight_decay);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed, uint64_t offset,
+                                      uint8_t *mask, void *stream) {
+  GCNX_REQUIRE(n >= 0 && (n == 0 || mask), GCNX_ERR_INVALID_ARG, "bernoulli: bad argument");
+  if (n == 0) return GCNX_OK;
+  hipLaunchKernelGGL(bernoulli_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
+                     as_stream(stream), n, keep, seed, offset, mask);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_normalize_csr_f64(const gcnx_csr *a, int64_t row_begin, const int32_t *row_sum,
+                                      const double *d_table, int64_t d_table_len, float *val_out,
+                                      int *status_flag, void *stream) {
+  GCNX_REQUIRE(a && row_sum && d_table && val_out && status_flag && d_table_len > 0 && row_begin >= 0,
+               GCNX_ERR_INVALID_ARG, "normalize: bad argument");
+  if (a->nnz == 0) return GCNX_OK;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)ceil_div(a->nnz, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), a->nnz, a->n_rows, row_begin, a->row_ptr, a->col_idx, a->val,
+                     row_sum, d_table, d_table_len, val_out, status_flag);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_coo_interleave_supports(int32_t n_sup, const int64_t *h_nnz,
+                                            const int32_t *const *h_row,
+                                            const int32_t *const *h_col, int64_t coord_stride,
+                                            const void *const *h_val, int val_is_f64,
+                                            int32_t *out_row, int32_t *out_col, void *out_val,
+                                            void *stream) {
+  GCNX_REQUIRE(n_sup > 0 && h_nnz && h_row && h_col && h_val && coord_stride >= 1,
+               GCNX_ERR_INVALID_ARG, "interleave: bad argument");
+  int64_t off = 0;
+  for (int32_t i = 0; i < n_sup; ++i) {
+    const int64_t nnz = h_nnz[i];
+    GCNX_REQUIRE(nnz >= 0, GCNX_ERR_INVALID_ARG, "interleave: negative nnz");
+    if (nnz == 0) continue;
+    GCNX_REQUIRE(h_row[i] && h_col[i] && h_val[i] && out_row && out_col && out_val,
+                 GCNX_ERR_INVALID_ARG, "interleave: null array");
+    void *ov = val_is_f64 ? static_cast<void *>(static_cast<double *>(out_val) + off)
+                          : static_cast<void *>(static_cast<float *>(out_val) + off);
+    hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)ceil_div(nnz, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), nnz, n_sup, i, h_row[i], h_col[i], coord_stride, h_val[i],
+                       val_is_f64, out_row + off, out_col + off, ov);
+    GCNX_CHECK_LAUNCH();
+    off += nnz;
+  }
+  return GCNX_OK;
+}

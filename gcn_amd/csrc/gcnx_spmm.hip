@@ -1,0 +1,346 @@
+// CSR SpMM for gfx950:  C = act(alpha * A' * B + beta * C)
+//
+// Work decomposition (merge-path flavoured row split): the nonzeros are cut into
+// fixed chunks of kChunk; ONE wavefront owns one chunk, whatever rows it covers,
+// so a hub row with 10^5 nonzeros costs the same per wavefront as 10^5 short
+// rows.  Inside a chunk the wavefront walks the nonzeros in slot order; lane l
+// owns VEC consecutive output columns, so one nonzero is one coalesced
+// 64*VEC*4-byte read of a B row and VEC FMAs per lane, and a row's sum is
+// formed sequentially in registers (no cross-lane reduction at this width).
+// col_idx / val are read 64 at a time, one per lane (coalesced), and broadcast
+// with v_readlane, which makes the B row address scalar: the gather is
+// `global_load_dwordx4 v, v_lane_off, s[row_base]`.  Row ends come from a
+// lane-held window of 64 row_ptr entries, so all control flow is scalar.
+//
+// Rows that lie wholly inside a chunk are stored straight to C.  A row cut by a
+// chunk boundary leaves one partial sum per chunk it touches in `partial`
+// (slot 0: the row began in an earlier chunk; slot 1: it begins here and runs
+// on); spmm_fixup_kernel adds them in chunk order and applies the epilogue, so
+// the result does not depend on scheduling.
+#include "gcnx_common.h"
+
+namespace gcnx {
+
+template <int VEC> struct vec_of;
+template <> struct vec_of<1> { typedef float type; };
+template <> struct vec_of<2> { typedef float __attribute__((ext_vector_type(2))) type; };
+template <> struct vec_of<4> { typedef float __attribute__((ext_vector_type(4))) type; };
+
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type vload(const float *p) {
+  return *reinterpret_cast<const typename vec_of<VEC>::type *>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float *p, typename vec_of<VEC>::type v) {
+  *reinterpret_cast<typename vec_of<VEC>::type *>(p) = v;
+}
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type vmax0(typename vec_of<VEC>::type v) {
+  if constexpr (VEC == 1) {
+    return fmaxf(v, 0.0f);
+  } else {
+    typename vec_of<VEC>::type o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = fmaxf(v[i], 0.0f);
+    return o;
+  }
+}
+
+__device__ __forceinline__ int rl_i(int v, int lane) {
+  return __builtin_amdgcn_readlane(v, lane);
+}
+__device__ __forceinline__ float rl_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+constexpr int kRowEndBeyond = 0x7fffffff;
+
+struct SpmmArgs {
+  int64_t n_rows;
+  int64_t nnz;
+  int64_t n_chunks;
+  const int64_t *row_ptr;
+  const int32_t *col_idx;
+  const float *val;
+  const int32_t *chunk_row;
+  const float *B;
+  int64_t ldb;
+  float *C;
+  int64_t ldc;
+  int32_t width;
+  int32_t pwidth;  // leading dimension of a partial slot
+  float alpha;
+  float beta;
+  const uint8_t *vmask;
+  const int64_t *mindex;
+  float mscale;
+  int relu;
+  float *partial;
+};
+
+template <int VEC>
+__device__ __forceinline__ void epilogue_store(const SpmmArgs &a, int64_t r, int col0,
+                                               typename vec_of<VEC>::type acc) {
+  float *dst = a.C + r * a.ldc + col0;
+  typename vec_of<VEC>::type out = acc * a.alpha;
+  if (a.beta != 0.0f) out += vload<VEC>(dst) * a.beta;
+  if (a.relu) out = vmax0<VEC>(out);
+  vstore<VEC>(dst, out);
+}
+
+template <int VEC, int U>
+__global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(const SpmmArgs a) {
+  typedef typename vec_of<VEC>::type V;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  if (c >= a.n_chunks) return;
+  const int col0 = (int)blockIdx.y * (kWave * VEC) + lane * VEC;
+  const bool active = col0 < a.width;
+
+  const int64_t n0 = c * (int64_t)kChunk;
+  const int64_t left = a.nnz - n0;
+  const int nk = left < (int64_t)kChunk ? (int)left : kChunk;
+
+  int64_t r = a.chunk_row[c];
+  int64_t rbase = r;
+  // Lane-held window: end (relative to n0) of rows rbase .. rbase+63.
+  auto load_row_ends = [&](int64_t rb) -> int {
+    const int64_t rr = rb + 1 + lane;
+    if (rr > a.n_rows) return kRowEndBeyond;
+    const int64_t e = a.row_ptr[rr] - n0;
+    return e > (int64_t)kChunk ? kChunk + 1 : (int)e;
+  };
+  int re_v = load_row_ends(rbase);
+  int re = rl_i(re_v, 0);
+  int rs;  // start of row r relative to n0 (negative: began in an earlier chunk)
+  {
+    const int64_t s = a.row_ptr[r] - n0;
+    rs = s < 0 ? -1 : (int)s;
+  }
+
+  V acc = V(0.0f);
+  float *const pslot = a.partial + (size_t)c * 2 * a.pwidth + col0;
+
+  auto close_row = [&]() {
+    if (active) {
+      if (rs < 0) {
+        vstore<VEC>(pslot, acc);
+      } else {
+        epilogue_store<VEC>(a, r, col0, acc);
+      }
+    }
+    acc = V(0.0f);
+    rs = re;
+    ++r;
+    int idx = (int)(r - rbase);
+    if (idx == kWave) {
+      rbase = r;
+      re_v = load_row_ends(rbase);
+      idx = 0;
+    }
+    re = rl_i(re_v, idx);
+  };
+
+  auto load_batch = [&](int kb, int &cols, float &vals) {
+    const int k = kb + lane;
+    cols = 0;
+    vals = 0.0f;
+    if (k < nk) {
+      const int64_t g = n0 + k;
+      cols = a.col_idx[g];
+      float v = a.val[g];
+      if (a.vmask) {
+        const int64_t mi = a.mindex ? a.mindex[g] : g;
+        v = a.vmask[mi] ? v * a.mscale : 0.0f;
+      }
+      vals = v;
+    }
+  };
+
+  int cols_n;
+  float vals_n;
+  load_batch(0, cols_n, vals_n);
+
+  for (int kb = 0; kb < nk; kb += kWave) {
+    const int cols = cols_n;
+    const float vals = vals_n;
+    if (kb + kWave < nk) load_batch(kb + kWave, cols_n, vals_n);
+    const int jn = (nk - kb) < kWave ? (nk - kb) : kWave;
+    for (int j = 0; j < jn; j += U) {
+      V b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = (j + u) < jn ? (j + u) : (jn - 1);
+        const int cc = rl_i(cols, jj);
+        const float *src = a.B + (int64_t)cc * a.ldb + col0;
+        b[u] = V(0.0f);
+        if (active) b[u] = vload<VEC>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j + u < jn) {
+          const int k = kb + j + u;
+          while (k == re) close_row();
+          const float v = rl_f(vals, j + u);
+          acc += b[u] * v;
+        }
+      }
+    }
+  }
+  while (re <= nk) close_row();
+  if (r < a.n_rows && rs < nk && active) {
+    vstore<VEC>(pslot + (rs < 0 ? 0 : a.pwidth), acc);
+  }
+}
+
+// One wavefront per chunk boundary c | c+1: if the row that owns the first
+// nonzero of chunk c+1 begins inside chunk c, this wavefront completes it.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
+  typedef typename vec_of<VEC>::type V;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  if (c + 1 >= a.n_chunks) return;
+  const int col0 = (int)blockIdx.y * (kWave * VEC) + lane * VEC;
+  if (col0 >= a.width) return;
+  const int64_t r = a.chunk_row[c + 1];
+  const int64_t start = a.row_ptr[r];
+  if (start >= (c + 1) * (int64_t)kChunk || start < c * (int64_t)kChunk) return;
+  const int64_t end = a.row_ptr[r + 1];
+  const int64_t cl = (end - 1) / kChunk;
+  const float *p = a.partial + col0;
+  V sum = vload<VEC>(p + ((size_t)c * 2 + 1) * a.pwidth);
+  for (int64_t cc = c + 1; cc <= cl; ++cc) sum += vload<VEC>(p + (size_t)cc * 2 * a.pwidth);
+  epilogue_store<VEC>(a, r, col0, sum);
+}
+
+// nnz == 0: every row is empty, C = act(beta * C).
+__global__ void spmm_empty_kernel(const SpmmArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_rows * (int64_t)a.width) return;
+  float *dst = a.C + (i / a.width) * a.ldc + (i % a.width);
+  float out = a.beta != 0.0f ? *dst * a.beta : 0.0f;
+  if (a.relu) out = fmaxf(out, 0.0f);
+  *dst = out;
+}
+
+// chunk_row[c] = last row whose first slot is <= c * kChunk (row 0 for c == 0,
+// n_rows for c == n_chunks).
+__global__ void chunk_table_kernel(int64_t n_rows, int64_t n_chunks,
+                                   const int64_t *__restrict__ row_ptr,
+                                   int32_t *__restrict__ chunk_row) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  if (c == 0) { chunk_row[0] = 0; return; }
+  if (c == n_chunks) { chunk_row[c] = (int32_t)n_rows; return; }
+  const int64_t target = c * (int64_t)kChunk;
+  int64_t lo = 0, hi = n_rows;  // invariant: row_ptr[lo] <= target < row_ptr[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] <= target) lo = mid; else hi = mid;
+  }
+  chunk_row[c] = (int32_t)lo;
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace gcnx
+
+using namespace gcnx;
+
+extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunk; }
+
+extern "C" int64_t gcnx_spmm_num_chunks(int64_t nnz) { return nnz <= 0 ? 0 : ceil_div(nnz, kChunk); }
+
+extern "C" int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream) {
+  GCNX_REQUIRE(a && chunk_row, GCNX_ERR_INVALID_ARG, "chunk_table: null argument");
+  GCNX_REQUIRE(a->n_rows >= 0 && a->nnz >= 0 && a->n_rows < INT32_MAX, GCNX_ERR_INVALID_ARG,
+               "chunk_table: bad shape");
+  const int64_t n_chunks = gcnx_spmm_num_chunks(a->nnz);
+  const int64_t threads = n_chunks + 1;
+  hipLaunchKernelGGL(chunk_table_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0,
+                     as_stream(stream), a->n_rows, n_chunks, a->row_ptr, chunk_row);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+static inline int32_t partial_ld(int32_t width) { return (width + 3) / 4 * 4; }
+
+extern "C" size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width) {
+  if (nnz <= 0 || width <= 0) return 0;
+  return (size_t)gcnx_spmm_num_chunks(nnz) * 2 * (size_t)partial_ld(width) * sizeof(float);
+}
+
+extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
+                                 int64_t ldb, float *C, int64_t ldc, int32_t width, float alpha,
+                                 float beta, const uint8_t *val_mask, const int64_t *mask_index,
+                                 float mask_scale, int fuse_relu, void *ws, size_t ws_bytes,
+                                 void *stream) {
+  GCNX_REQUIRE(a && C, GCNX_ERR_INVALID_ARG, "spmm: null matrix or output");
+  GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
+               GCNX_ERR_INVALID_ARG, "spmm: negative size");
+  GCNX_REQUIRE(a->n_rows < INT32_MAX && a->n_cols < INT32_MAX, GCNX_ERR_UNSUPPORTED,
+               "spmm: more than 2^31-1 rows or columns");
+  if (a->n_rows == 0 || width == 0) return GCNX_OK;
+  GCNX_REQUIRE(ldc >= width, GCNX_ERR_INVALID_ARG, "spmm: ldc < width");
+  hipStream_t st = as_stream(stream);
+
+  SpmmArgs k;
+  k.n_rows = a->n_rows;
+  k.nnz = a->nnz;
+  k.n_chunks = gcnx_spmm_num_chunks(a->nnz);
+  k.row_ptr = a->row_ptr;
+  k.col_idx = a->col_idx;
+  k.val = a->val;
+  k.chunk_row = chunk_row;
+  k.B = B;
+  k.ldb = ldb;
+  k.C = C;
+  k.ldc = ldc;
+  k.width = width;
+  k.pwidth = partial_ld(width);
+  k.alpha = alpha;
+  k.beta = beta;
+  k.vmask = val_mask;
+  k.mindex = mask_index;
+  k.mscale = mask_scale;
+  k.relu = fuse_relu;
+  k.partial = static_cast<float *>(ws);
+
+  if (a->nnz == 0) {
+    const int64_t total = a->n_rows * (int64_t)width;
+    hipLaunchKernelGGL(spmm_empty_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, k);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+  GCNX_REQUIRE(a->row_ptr && a->col_idx && a->val && chunk_row && B, GCNX_ERR_INVALID_ARG,
+               "spmm: null array");
+  GCNX_REQUIRE(ldb >= width, GCNX_ERR_INVALID_ARG, "spmm: ldb < width");
+  const size_t need = gcnx_spmm_workspace_bytes(a->nnz, width);
+  GCNX_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GCNX_ERR_WORKSPACE,
+               "spmm: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
+  GCNX_REQUIRE(k.n_chunks / kWavesPerBlock < INT32_MAX, GCNX_ERR_UNSUPPORTED, "spmm: too many chunks");
+
+  const bool v4 = (width % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C);
+  const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
+  if (v4) {
+    const unsigned gy = (unsigned)ceil_div(width, kWave * 4);
+    hipLaunchKernelGGL((spmm_chunk_kernel<4, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    GCNX_CHECK_LAUNCH();
+    if (k.n_chunks > 1) {
+      hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+      GCNX_CHECK_LAUNCH();
+    }
+  } else {
+    const unsigned gy = (unsigned)ceil_div(width, kWave);
+    hipLaunchKernelGGL((spmm_chunk_kernel<1, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    GCNX_CHECK_LAUNCH();
+    if (k.n_chunks > 1) {
+      hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+      GCNX_CHECK_LAUNCH();
+    }
+  }
+  return GCNX_OK;
+}

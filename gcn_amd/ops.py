@@ -1,0 +1,255 @@
+"""Python entry points of the HIP kernels + their autograd glue.
+
+torch is used for tensor ownership, streams and the autograd tape only; every
+product, reduction and update below runs in ``libgcnhip.so`` through ctypes.
+All functions raise on CPU tensors -- there is no fallback path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .sparse import Csr, WORKSPACE, _ptr, _stream
+
+
+def _check_dense(t, name):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError("%s must be a CUDA (ROCm) tensor; gcn_amd has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("%s must be a row-major 2-D tensor" % name)
+
+
+# ------------------------------------------------------------------------ SpMM
+def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False):
+    """``out = act(alpha * A' @ b + beta * out)`` with ``A`` a :class:`Csr`.
+    ``mask`` (uint8, in the order of the tuple ``A`` was built from) applies
+    sparse dropout to the values on the fly.  Replaces ``dot(x, y, sparse=True)``
+    (reference gcn/layers.py:30-33) and ``sparse_dropout`` (:21-27)."""
+    lib = _lib.load()
+    _check_dense(b, "b")
+    if b.shape[0] != a.n_cols:
+        raise ValueError("shape mismatch: A is %s, b is %s" % (a.shape, tuple(b.shape)))
+    if b.device != a.device:
+        raise ValueError("A and b live on different devices")
+    width = b.shape[1]
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an existing out")
+        out = torch.empty((a.n_rows, width), dtype=torch.float32, device=b.device)
+    else:
+        _check_dense(out, "out")
+        if tuple(out.shape) != (a.n_rows, width):
+            raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (a.n_rows, width)))
+    midx = None
+    if mask is not None:
+        if mask.dtype != torch.uint8 or mask.numel() != a.nnz or mask.device != a.device:
+            raise ValueError("mask must be uint8 with one byte per nonzero on A's device")
+        midx = a.input_index
+    with torch.cuda.device(a.device):
+        need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+        ws = WORKSPACE.get(need, a.device)
+        _lib.check(lib.gcnx_spmm_csr_f32(
+            a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+            width, float(alpha), float(beta), _ptr(mask), _ptr(midx), float(mask_scale),
+            1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+class _SpmmFn(torch.autograd.Function):
+    """y = act(A' @ b).  Gradient w.r.t. b only: the sparse operands of the
+    reference are placeholders, no gradient reaches their values
+    (reference gcn/models.py:58)."""
+
+    @staticmethod
+    def forward(ctx, b, a, mask, mask_scale, relu):
+        y = spmm(a, b, mask=mask, mask_scale=mask_scale, relu=relu)
+        ctx.a = a
+        ctx.mask = mask
+        ctx.mask_scale = mask_scale
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            dy = relu_dropout_bwd(y, dy)
+        db = spmm(ctx.a.transpose(), dy, mask=ctx.mask, mask_scale=ctx.mask_scale)
+        return db, None, None, None, None
+
+
+def spmm_autograd(a, b, mask=None, mask_scale=1.0, relu=False):
+    return _SpmmFn.apply(b, a, mask, mask_scale, relu)
+
+
+# ------------------------------------------------------------------------ GEMM
+def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False):
+    """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
+    ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35)."""
+    lib = _lib.load()
+    _check_dense(a, "a")
+    _check_dense(b, "b")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError("inner dimensions differ: %d vs %d" % (K, Kb))
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("beta != 0 needs an existing out")
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _check_dense(out, "out")
+        if tuple(out.shape) != (M, N):
+            raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (M, N)))
+    with torch.cuda.device(a.device):
+        need = lib.gcnx_gemm_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
+        ws = WORKSPACE.get(need, a.device)
+        _lib.check(lib.gcnx_gemm_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                     _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
+                                     float(beta), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+class _GemmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = gemm(dy, b, trans_b=True) if ctx.needs_input_grad[0] else None
+        db = gemm(a, dy, trans_a=True) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def gemm_autograd(a, b):
+    return _GemmFn.apply(a, b)
+
+
+# ------------------------------------------------------------- loss / accuracy
+def masked_softmax_xent(logits, labels, mask, want_grad=True):
+    """Returns ``(loss_acc, grad)``: ``loss_acc`` is a 2-element device tensor
+    ``[loss, accuracy]`` (reference gcn/metrics.py:4-20), ``grad`` = dloss/dlogits
+    or None."""
+    lib = _lib.load()
+    _check_dense(logits, "logits")
+    _check_dense(labels, "labels")
+    n, c = logits.shape
+    if tuple(labels.shape) != (n, c):
+        raise ValueError("labels shape %s != logits shape %s" % (tuple(labels.shape), (n, c)))
+    if mask.dtype != torch.uint8 or mask.numel() != n or mask.device != logits.device:
+        raise ValueError("mask must be uint8 [n] on the logits' device")
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    with torch.cuda.device(logits.device):
+        need = lib.gcnx_xent_workspace_bytes(n)
+        ws = WORKSPACE.get(need, logits.device)
+        _lib.check(lib.gcnx_masked_softmax_xent_f32(
+            n, c, _ptr(logits), logits.stride(0), _ptr(labels), labels.stride(0), _ptr(mask),
+            _ptr(out), _ptr(grad), grad.stride(0) if grad is not None else 0, _ptr(ws),
+            ws.numel(), _stream()))
+    return out, grad
+
+
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, mask):
+        out, grad = masked_softmax_xent(logits.contiguous(), labels, mask, want_grad=True)
+        ctx.save_for_backward(grad)
+        loss = out[0].clone()
+        acc = out[1].clone()
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None, None
+
+
+def masked_softmax_xent_autograd(logits, labels, mask):
+    """``(loss, accuracy)`` as 0-dim tensors; ``loss`` is differentiable."""
+    return _XentFn.apply(logits, labels, mask)
+
+
+# ------------------------------------------------------------------ elementwise
+def bernoulli_mask(n, keep, seed, offset, device):
+    """uint8 mask, byte k = 1 with probability ``keep``, a pure function of
+    (seed, offset + k) (Philox4x32-10)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("bernoulli_mask needs a CUDA (ROCm) device")
+    mask = torch.empty(int(n), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gcnx_bernoulli_mask_u8(int(n), float(keep), int(seed) & (2 ** 64 - 1),
+                                              int(offset), _ptr(mask), _stream()))
+    return mask
+
+
+def dropout_dense(x, mask, scale, out=None):
+    lib = _lib.load()
+    if x.device.type != "cuda" or x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous float32 CUDA tensor")
+    if mask.dtype != torch.uint8 or mask.numel() != x.numel():
+        raise ValueError("mask must be uint8 with one byte per element")
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gcnx_dropout_dense_f32(x.numel(), _ptr(x), _ptr(mask), float(scale),
+                                              _ptr(out), _stream()))
+    return out
+
+
+def relu_dropout_bwd(y, dy, mask=None, scale=1.0):
+    """``dx = (y > 0 ? dy : 0)`` optionally times the dropout mask and scale."""
+    lib = _lib.load()
+    if y.device.type != "cuda" or not y.is_contiguous() or not dy.is_contiguous():
+        raise ValueError("y and dy must be contiguous CUDA tensors")
+    dx = torch.empty_like(dy)
+    with torch.cuda.device(y.device):
+        _lib.check(lib.gcnx_relu_dropout_bwd_f32(y.numel(), _ptr(y), _ptr(dy), _ptr(mask),
+                                                 float(scale), _ptr(dx), _stream()))
+    return dx
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, scale):
+        ctx.mask = mask
+        ctx.scale = scale
+        return dropout_dense(x.contiguous(), mask, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout_dense(dy.contiguous(), ctx.mask, ctx.scale), None, None
+
+
+def dropout_dense_autograd(x, mask, scale):
+    return _DropoutFn.apply(x, mask, scale)
+
+
+def adam_step(w, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """In-place TF-style Adam (reference gcn/models.py:142); ``t`` counts from 1."""
+    lib = _lib.load()
+    for name, x in (("w", w), ("grad", grad), ("m", m), ("v", v)):
+        if x.device.type != "cuda" or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.gcnx_adam_step_f32(w.numel(), _ptr(w), _ptr(grad), _ptr(m), _ptr(v),
+                                          float(lr), float(beta1), float(beta2), float(eps),
+                                          float(weight_decay), int(t), _stream()))
+    return w
+
+
+__all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",
+           "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
+           "dropout_dense_autograd", "relu_dropout_bwd", "adam_step"]

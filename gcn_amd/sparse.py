@@ -1,0 +1,177 @@
+"""Device-resident CSR matrices built through the C ABI.
+
+The reference hands TensorFlow an unsorted COO tuple on every ``sess.run``
+(gcn/utils.py:143-144); here the tuple is uploaded once, ordered on the device
+into CSR (``gcnx_csr_from_coo``) and kept resident together with its chunk
+table and, on demand, its exact transpose.  torch only owns the memory.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(device):
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("gcn_amd runs on the GPU only (got device %s); "
+                           "there is no CPU path" % (dev,))
+    return dev
+
+
+class _Workspace(object):
+    """Per-device scratch buffer, grown on demand and then reused, so the
+    compute calls never allocate once warm."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._buf[key] = None
+            n = max(int(nbytes), 256)
+            buf = torch.empty(n, dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+WORKSPACE = _Workspace()
+
+
+class Csr(object):
+    """CSR on the device: ``row_ptr`` int64 [n_rows+1], ``col_idx`` int32 [nnz],
+    ``val`` fp32 [nnz]; rows ordered by column, duplicates in input order.
+    ``input_index[slot]`` is the position of the entry in the tuple the matrix
+    was built from (dropout masks are drawn in that order,
+    reference gcn/layers.py:21-27)."""
+
+    def __init__(self, n_rows, n_cols, row_ptr, col_idx, val, input_index=None):
+        self.n_rows = int(n_rows)
+        self.n_cols = int(n_cols)
+        self.nnz = int(col_idx.numel())
+        self.row_ptr = row_ptr
+        self.col_idx = col_idx
+        self.val = val
+        self.input_index = input_index
+        self.device = row_ptr.device
+        self._t = None
+        self._struct = _lib.CsrStruct(self.n_rows, self.n_cols, self.nnz,
+                                      row_ptr.data_ptr(), col_idx.data_ptr(), val.data_ptr())
+        lib = _lib.load()
+        n_chunks = lib.gcnx_spmm_num_chunks(self.nnz)
+        self.chunk_row = torch.empty(n_chunks + 1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gcnx_spmm_chunk_table(C.byref(self._struct), _ptr(self.chunk_row), _stream()))
+
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_cols)
+
+    def struct_ref(self):
+        return C.byref(self._struct)
+
+    # ---------------------------------------------------------------- builders
+    @classmethod
+    def from_coo(cls, rows, cols, vals, shape, device="cuda", coords=None):
+        """Build from COO arrays (numpy or torch).  ``vals`` may be fp32 or fp64;
+        fp64 is rounded to fp32 after ordering, as feeding an fp64 tuple to a
+        ``tf.float32`` sparse placeholder does (reference gcn/train_normal.py:50).
+        ``coords`` (an [nnz,2] int32 array) may be given instead of rows/cols."""
+        dev = _require_cuda(device)
+        lib = _lib.load()
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if coords is not None:
+            co = torch.as_tensor(np.ascontiguousarray(coords) if isinstance(coords, np.ndarray) else coords)
+            co = co.to(device=dev, dtype=torch.int32).contiguous()
+            if co.dim() != 2 or co.shape[1] != 2:
+                raise ValueError("coords must be [nnz, 2]")
+            nnz = co.shape[0]
+            row_p = co.data_ptr()
+            col_p = co.data_ptr() + 4
+            stride = 2
+            keep = (co,)
+        else:
+            r = torch.as_tensor(rows).to(device=dev, dtype=torch.int32).contiguous()
+            c = torch.as_tensor(cols).to(device=dev, dtype=torch.int32).contiguous()
+            if r.shape != c.shape or r.dim() != 1:
+                raise ValueError("rows and cols must be 1-D and equally long")
+            nnz = r.numel()
+            row_p, col_p, stride = r.data_ptr(), c.data_ptr(), 1
+            keep = (r, c)
+        v = torch.as_tensor(vals)
+        if v.dtype not in (torch.float32, torch.float64):
+            v = v.to(torch.float64)
+        v = v.to(dev).contiguous()
+        if v.numel() != nnz:
+            raise ValueError("values and coordinates differ in length")
+        row_ptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        col_idx = torch.empty(nnz, dtype=torch.int32, device=dev)
+        val = torch.empty(nnz, dtype=torch.float32, device=dev)
+        perm = torch.empty(nnz, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            need = lib.gcnx_csr_from_coo_workspace_bytes(n_rows, nnz)
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gcnx_csr_from_coo(
+                n_rows, n_cols, nnz, C.c_void_p(row_p), C.c_void_p(col_p), stride, _ptr(v),
+                1 if v.dtype == torch.float64 else 0, _ptr(row_ptr), _ptr(col_idx), _ptr(val),
+                _ptr(perm), _ptr(ws), ws.numel(), _stream()))
+        del keep, ws
+        return cls(n_rows, n_cols, row_ptr, col_idx, val, perm)
+
+    @classmethod
+    def from_tuple(cls, t, device="cuda"):
+        """From the reference's sparse tuple ``(coords[nnz,2], values, shape)``
+        (gcn/utils.py:93-109)."""
+        coords, values, shape = t
+        coords = np.ascontiguousarray(np.asarray(coords).reshape(-1, 2).astype(np.int32, copy=False))
+        return cls.from_coo(None, None, np.ascontiguousarray(values), shape, device, coords=coords)
+
+    @classmethod
+    def from_scipy(cls, m, device="cuda"):
+        m = m.tocoo()
+        return cls.from_coo(m.row, m.col, m.data, m.shape, device)
+
+    # --------------------------------------------------------------- transpose
+    def transpose(self):
+        """Exact transpose (cached).  Its ``input_index`` still refers to the
+        tuple this matrix was built from, so a dropout mask drawn for the
+        forward product can be reused by the backward one."""
+        if self._t is not None:
+            return self._t
+        lib = _lib.load()
+        dev = self.device
+        t_row_ptr = torch.empty(self.n_cols + 1, dtype=torch.int64, device=dev)
+        t_col_idx = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        t_val = torch.empty(self.nnz, dtype=torch.float32, device=dev)
+        t_perm = torch.empty(self.nnz, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            need = lib.gcnx_csr_transpose_workspace_bytes(self.n_rows, self.n_cols, self.nnz)
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gcnx_csr_transpose(self.struct_ref(), _ptr(t_row_ptr), _ptr(t_col_idx),
+                                              _ptr(t_val), _ptr(t_perm), _ptr(ws), ws.numel(),
+                                              _stream()))
+        del ws
+        idx = self.input_index[t_perm] if self.input_index is not None else t_perm
+        t = Csr(self.n_cols, self.n_rows, t_row_ptr, t_col_idx, t_val, idx)
+        t._t = self
+        self._t = t
+        return t
+
+    # ------------------------------------------------------------------ export
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val.cpu().numpy(), self.col_idx.cpu().numpy(),
+                              self.row_ptr.cpu().numpy()), shape=self.shape)

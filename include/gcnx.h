@@ -1,0 +1,236 @@
+/*
+ * gcnx -- C ABI of the MI355X (gfx950) GCN propagation kernels.
+ *
+ * The reference (harleyiscoding/gcn, a TensorFlow-1.x Kipf GCN) has no FFI of
+ * its own: its propagation path is a handful of TensorFlow ops reached from
+ * gcn/layers.py.  Each entry point below replaces one of those call sites; the
+ * citation after "replaces:" is the reference file:line (relative to
+ * gcn-master/).  The host-side mirror of the reference's Python API
+ * (gcn_amd/layers.py, models.py, utils.py) calls these through ctypes.
+ *
+ * Conventions
+ *   - Every function returns GCNX_OK (0) or a negative gcnx_status; it never
+ *     throws, aborts or frees caller memory.  gcnx_last_error() returns a
+ *     thread-local description of the last failure.
+ *   - All array arguments are DEVICE pointers borrowed from the caller, unless
+ *     the name starts with h_.  The caller keeps them alive until the stream
+ *     has been synchronised.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Compute entry points are asynchronous and stream-ordered and never
+ *     allocate; scratch memory comes in through (ws, ws_bytes), sized by the
+ *     matching *_workspace_bytes query.  Builder entry points (csr_from_coo,
+ *     csr_transpose, rmat_*) synchronise the stream once before returning so
+ *     that they can report malformed input.
+ *   - Row-major dense matrices with an explicit leading dimension in elements.
+ *   - Indices: row_ptr is int64 (nnz may exceed 2^31), col_idx int32.
+ */
+#ifndef GCNX_H
+#define GCNX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCNX_ABI_VERSION 1
+
+typedef enum gcnx_status {
+  GCNX_OK = 0,
+  GCNX_ERR_INVALID_ARG = -1,  /* null pointer, negative size, bad stride ... */
+  GCNX_ERR_WORKSPACE = -2,    /* ws_bytes smaller than the query's answer    */
+  GCNX_ERR_INDEX_RANGE = -3,  /* a coordinate outside [0,n_rows) x [0,n_cols) */
+  GCNX_ERR_HIP = -4,          /* a HIP runtime call failed                   */
+  GCNX_ERR_UNSUPPORTED = -5
+} gcnx_status;
+
+/* CSR matrix resident on the device.  Entries of a row are ordered by column,
+ * duplicates kept in input order. */
+typedef struct gcnx_csr {
+  int64_t n_rows;
+  int64_t n_cols;
+  int64_t nnz;
+  const int64_t *row_ptr; /* [n_rows + 1] */
+  const int32_t *col_idx; /* [nnz] */
+  const float *val;       /* [nnz] */
+} gcnx_csr;
+
+int gcnx_abi_version(void);
+const char *gcnx_last_error(void);
+/* Number of nonzeros one wavefront owns in the SpMM kernels (the unit of the
+ * chunk table below). */
+int gcnx_spmm_chunk_nnz(void);
+
+/* ---- CSR construction ---------------------------------------------------
+ * replaces: the sparse tuple -> tf.sparse_placeholder(tf.float32) feed,
+ * gcn/utils.py:93-109,143-144 and gcn/train_normal.py:50-51 (TensorFlow takes
+ * the unsorted COO tuple on every step; here it is turned into a resident CSR
+ * once).  Stable order by (row, col); duplicates kept; fp64 values rounded to
+ * fp32 (nearest-even) after ordering.  Coordinates are read as
+ * row[k*coord_stride], col[k*coord_stride], so an interleaved [nnz,2] int32
+ * array is (coords, coords+1, 2).  perm_out[slot] = input position (nullable).
+ */
+size_t gcnx_csr_from_coo_workspace_bytes(int64_t n_rows, int64_t nnz);
+int gcnx_csr_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                      const int32_t *row, const int32_t *col,
+                      int64_t coord_stride, const void *val, int val_is_f64,
+                      int64_t *row_ptr, int32_t *col_idx, float *val_out,
+                      int64_t *perm_out, void *ws, size_t ws_bytes,
+                      void *stream);
+
+/* Exact structural transpose (no arithmetic on the values).
+ * replaces: adjoint_a=True of TensorFlow's SparseTensorDenseMatMul gradient,
+ * created by optimizer.minimize at gcn/models.py:58 (backward of
+ * gcn/layers.py:219 and :215).  perm_out[slot of A^T] = slot of A (nullable). */
+size_t gcnx_csr_transpose_workspace_bytes(int64_t n_rows, int64_t n_cols,
+                                          int64_t nnz);
+int gcnx_csr_transpose(const gcnx_csr *a, int64_t *t_row_ptr,
+                       int32_t *t_col_idx, float *t_val, int64_t *perm_out,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* Chunk table for the SpMM kernels: chunk_row[c] = row that owns nonzero
+ * c * gcnx_spmm_chunk_nnz().  n_chunks = ceil(nnz / chunk).  Built once per
+ * matrix.  chunk_row has n_chunks + 1 entries (the last is n_rows). */
+int64_t gcnx_spmm_num_chunks(int64_t nnz);
+int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream);
+
+/* ---- SpMM:  C = act(alpha * A' * B + beta * C) ----------------------------
+ * replaces: dot(x, y, sparse=True) = tf.sparse_tensor_dense_matmul,
+ * gcn/layers.py:30-33, at its call sites :219 (A_hat * P), :215-216 and :123
+ * (X * W), and, given the transposed CSR, the backward products A_hat^T * dH and
+ * X^T * dZ (gcn/models.py:58).  A' is A with the sparse-dropout mask applied on
+ * the fly (replaces sparse_dropout, gcn/layers.py:21-27): with val_mask != NULL
+ * the value of slot k is  val_mask[mask_index ? mask_index[k] : k] ?
+ * val[k] * mask_scale : 0.  fuse_relu != 0 applies max(0, .) before the store
+ * (gcn/layers.py:226).  beta == 0 never reads C.
+ * Sums are formed in fp32 in slot order inside a chunk; rows that span several
+ * chunks are completed from per-chunk partial sums in chunk order, so results
+ * are bitwise reproducible run to run.
+ */
+size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width);
+int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                      const float *B, int64_t ldb, float *C, int64_t ldc,
+                      int32_t width, float alpha, float beta,
+                      const uint8_t *val_mask, const int64_t *mask_index,
+                      float mask_scale, int fuse_relu, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* ---- Multi-support sum  C = act(sum_i A_i * P_i)  as ONE product -----------
+ * replaces: the loop over supports plus tf.add_n, gcn/layers.py:213-221 (and
+ * :195-198).  The supports are merged into one COO over interleaved columns,
+ * col' = col * n_sup + i, so that  sum_i A_i * P_i = A_cat * reshape(P_cat)
+ * where P_cat[N, n_sup*width] = x * [W_0 | ... | W_{n-1}]; the result is a
+ * plain gcnx_spmm_csr_f32 call that accumulates across supports in registers.
+ * This entry point writes the merged coordinates; h_* arrays are HOST arrays of
+ * n_sup device pointers / sizes.  Outputs have sum(h_nnz) entries.
+ */
+int gcnx_coo_interleave_supports(int32_t n_sup, const int64_t *h_nnz,
+                                 const int32_t *const *h_row,
+                                 const int32_t *const *h_col,
+                                 int64_t coord_stride,
+                                 const void *const *h_val, int val_is_f64,
+                                 int32_t *out_row, int32_t *out_col,
+                                 void *out_val, void *stream);
+
+/* ---- dense product  C = alpha * op(A) * op(B) + beta * C -------------------
+ * replaces: dot(x, y, sparse=False) = tf.matmul, gcn/layers.py:35 (call sites
+ * :215 for H' * W and :123), and its two gradients H'^T * dP and dP * W^T
+ * (gcn/models.py:58).  fp32 in, fp32 accumulate.  op(A) is M x K, op(B) K x N.
+ * The K-reduction of a transposed-A product over a very tall A is split across
+ * workgroups and completed from partial tiles in a fixed order (ws).
+ */
+size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N,
+                                 int64_t K);
+int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                  const float *A, int64_t lda, const float *B, int64_t ldb,
+                  float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* ---- glue kernels of one training step ------------------------------------ */
+
+/* replaces: masked_softmax_cross_entropy + masked_accuracy, gcn/metrics.py:4-20.
+ * out_loss_acc[0] = mean_i(CE_i * mask_i / mean(mask)), out_loss_acc[1] = masked
+ * accuracy (first maximum wins), grad (nullable) = d loss / d logits.
+ * ws: gcnx_xent_workspace_bytes(n). */
+size_t gcnx_xent_workspace_bytes(int64_t n);
+int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const float *logits,
+                                 int64_t ld, const float *labels, int64_t ldl,
+                                 const uint8_t *mask, float *out_loss_acc,
+                                 float *grad, int64_t ldg, void *ws,
+                                 size_t ws_bytes, void *stream);
+
+/* replaces: tf.nn.dropout on a dense activation, gcn/layers.py:210,120.
+ * out = mask ? x * scale : 0; mask is one byte per element (the caller draws
+ * it, so a parity run can share it).  In place allowed. */
+int gcnx_dropout_dense_f32(int64_t n, const float *x, const uint8_t *mask,
+                           float scale, float *out, void *stream);
+
+/* Counter-based Bernoulli(keep) mask: byte k = (uniform(seed, offset + k) <
+ * keep).  Philox4x32-10; the same (seed, offset) gives the same mask on any
+ * device count.  replaces: tf.random_uniform in gcn/layers.py:24. */
+int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed,
+                           uint64_t offset, uint8_t *mask, void *stream);
+
+/* dx = (y > 0 ? dy : 0) [* mask * scale]: backward of act=relu
+ * (gcn/layers.py:226) fused with the backward of the next layer's dropout
+ * (gcn/layers.py:210).  y is the relu OUTPUT.  mask nullable. */
+int gcnx_relu_dropout_bwd_f32(int64_t n, const float *y, const float *dy,
+                              const uint8_t *mask, float scale, float *dx,
+                              void *stream);
+
+/* replaces: tf.train.AdamOptimizer(lr).minimize, gcn/models.py:142,58, with
+ * weight decay folded in as grad + weight_decay * w (gradient of
+ * weight_decay * l2_loss(w), gcn/models.py:148-149).  t counts from 1. */
+int gcnx_adam_step_f32(int64_t n, float *w, const float *grad, float *m,
+                       float *v, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int64_t t, void *stream);
+
+/* ---- degree normalisation on the device -----------------------------------
+ * replaces: normalize_adj / preprocess_adj, gcn/utils.py:122-135, for graphs
+ * too large for the host.  `a` holds local rows [row_begin, row_begin+n_rows)
+ * of a matrix with a symmetric pattern and symmetric values (A + I of an
+ * undirected graph).  The entry at (r, c) becomes
+ *   fp32( fp64( fp64(a * d[r]) * d[c] ) ),  d[i] = d_table[row_sum[i]],
+ * the two fp64 roundings of the reference's (A.D)^T.D.  d_table is computed on
+ * the host as numpy.power(k, -0.5) for the integer row sums k (entry 0 = 0, the
+ * reference's inf -> 0 rule); row_sum is indexed by GLOBAL vertex id.
+ * *status_flag (device int, zeroed by the caller) is set to 1 if a row sum
+ * falls outside the table.
+ */
+int gcnx_normalize_csr_f64(const gcnx_csr *a, int64_t row_begin,
+                           const int32_t *row_sum, const double *d_table,
+                           int64_t d_table_len, float *val_out,
+                           int *status_flag, void *stream);
+
+/* ---- synthetic RMAT graphs --------------------------------------------------
+ * No counterpart in the reference (its inputs are the Planetoid files); this is
+ * the generator of the benchmark inputs.  Edge e of 2^scale * edge_factor
+ * undirected edges is drawn from Philox4x32-10 keyed by (seed, e) with
+ * quadrant probabilities (a, b, c, 1-a-b-c), vertex ids are scrambled by a
+ * seeded bijection, self-loops dropped.  Writes, for the rows
+ * [row_begin, row_end) only, both directions of every edge as 64-bit keys
+ * (row << 32 | col), unsorted and with duplicates, into keys_out (capacity
+ * `capacity`); *h_count receives the number written (or needed, if larger than
+ * capacity, in which case the status is GCNX_ERR_WORKSPACE).
+ */
+int gcnx_rmat_edges(int32_t scale, int64_t edge_begin, int64_t edge_end,
+                    double a, double b, double c, uint64_t seed,
+                    int64_t row_begin, int64_t row_end, uint64_t *keys_out,
+                    int64_t capacity, int64_t *h_count, void *ws, void *stream);
+size_t gcnx_rmat_workspace_bytes(void);
+
+/* Sort + de-duplicate 64-bit (row << 32 | col) keys, add the diagonal (A + I),
+ * and emit a CSR over local rows [row_begin, row_end) with all values 1.0.
+ * *h_nnz receives the number of entries.  col_idx/val capacity = n_keys +
+ * (row_end - row_begin). */
+size_t gcnx_csr_from_keys_workspace_bytes(int64_t n_keys, int64_t n_local_rows);
+int gcnx_csr_from_keys(uint64_t *keys, int64_t n_keys, int64_t row_begin,
+                       int64_t row_end, int add_identity, int64_t *row_ptr,
+                       int32_t *col_idx, float *val, int64_t *h_nnz, void *ws,
+                       size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNX_H */

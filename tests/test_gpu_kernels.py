@@ -1,0 +1,280 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (ctypes) and
+checked against the CPU oracle on the same seeded inputs.
+
+Bars: CSR construction / transpose / masks / RMAT keys are bit-exact; fp32
+products are within 1e-5 relative to the size of the summed terms (helpers.py).
+"""
+import numpy as np
+import pytest
+
+from helpers import RTOL, assert_close_to_f64, random_coo, rel_maxnorm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import oracle
+    from gcn_amd import ops, sparse
+    assert torch.cuda.is_available()
+    oracle.build()
+    return dict(torch=torch, oracle=oracle, ops=ops, sparse=sparse, dev=torch.device("cuda:0"))
+
+
+def _csr_np(csr):
+    return (csr.row_ptr.cpu().numpy(), csr.col_idx.cpu().numpy(), csr.val.cpu().numpy(),
+            csr.input_index.cpu().numpy())
+
+
+# ------------------------------------------------------------------ CSR build
+@pytest.mark.parametrize("n_rows,n_cols,nnz,f64", [
+    (1, 1, 1, True), (5, 3, 0, True), (64, 64, 300, True), (1000, 777, 20000, False),
+    (3000, 3000, 200000, True), (10, 100000, 5000, True),
+])
+def test_csr_from_coo_bit_exact(env, n_rows, n_cols, nnz, f64):
+    rng = np.random.RandomState(n_rows * 7 + nnz)
+    rows, cols, vals = random_coo(rng, n_rows, n_cols, nnz, dup_frac=0.1)
+    if not f64:
+        vals = vals.astype(np.float32)
+    ref = env["oracle"].csr_from_coo(rows, cols, vals, (n_rows, n_cols))
+    got = _csr_np(env["sparse"].Csr.from_coo(rows, cols, vals, (n_rows, n_cols), env["dev"]))
+    for g, r, name in zip(got, ref, ("row_ptr", "col_idx", "val", "perm")):
+        assert g.dtype == r.dtype, name
+        assert np.array_equal(g.view(np.uint8), r.view(np.uint8)), name
+
+
+def test_csr_from_coo_rejects_out_of_range(env):
+    from gcn_amd._lib import GcnxError, ERR_INDEX_RANGE
+    with pytest.raises(GcnxError) as ei:
+        env["sparse"].Csr.from_coo([0, 5], [0, 1], [1.0, 2.0], (3, 3), env["dev"])
+    assert ei.value.code == ERR_INDEX_RANGE
+
+
+@pytest.mark.parametrize("ds", ["cora", "citeseer"])
+def test_csr_of_golden_ahat(env, ds, golden_dir):
+    """The reference's own preprocess_adj output -> device CSR: same entries as
+    the canonical (row, col) order of the tuple, values rounded to fp32."""
+    import hashlib
+    import json
+    import os
+    z = np.load(os.path.join(golden_dir, "ahat_%s.npz" % ds))
+    known = json.load(open(os.path.join(golden_dir, "generated_answers.json")))[ds]
+    csr = env["sparse"].Csr.from_tuple((z["coords"], z["values"], tuple(z["shape"])), env["dev"])
+    row_ptr, col_idx, val, _ = _csr_np(csr)
+    rows = np.repeat(np.arange(csr.n_rows, dtype=np.int32), np.diff(row_ptr))
+    coords = np.stack([rows, col_idx], axis=1).astype(np.int32)
+    assert hashlib.sha256(np.ascontiguousarray(coords).tobytes()).hexdigest() == known["ahat_coords_sha_sorted"]
+    assert hashlib.sha256(val.astype("<f4").tobytes()).hexdigest() == known["ahat_vals_f32_sha_sorted"]
+
+
+@pytest.mark.parametrize("n_rows,n_cols,nnz", [(1, 1, 1), (7, 5, 0), (500, 300, 9000), (4000, 4000, 150000)])
+def test_transpose_bit_exact(env, n_rows, n_cols, nnz):
+    rng = np.random.RandomState(nnz + 3)
+    rows, cols, vals = random_coo(rng, n_rows, n_cols, nnz)
+    a = env["sparse"].Csr.from_coo(rows, cols, vals, (n_rows, n_cols), env["dev"])
+    rp, ci, v, perm = _csr_np(a)
+    t_ref = env["oracle"].csr_transpose(rp, ci, v, n_cols)
+    t = a.transpose()
+    trp, tci, tv, tidx = _csr_np(t)
+    assert np.array_equal(trp, t_ref[0])
+    assert np.array_equal(tci, t_ref[1])
+    assert np.array_equal(tv.view(np.uint32), t_ref[2].view(np.uint32))
+    # input_index of the transpose = original tuple position of each slot
+    assert np.array_equal(tidx, perm[t_ref[3]])
+    assert t.transpose() is a
+
+
+# ------------------------------------------------------------------------ SpMM
+def _spmm_case(env, n_rows, n_cols, nnz, width, hub=(), empty=(), seed=0, **kw):
+    torch = env["torch"]
+    rng = np.random.RandomState(seed + width + nnz)
+    rows, cols, vals = random_coo(rng, n_rows, n_cols, nnz, hub_rows=hub, empty_rows=empty)
+    a = env["sparse"].Csr.from_coo(rows, cols, vals, (n_rows, n_cols), env["dev"])
+    b = rng.standard_normal((n_cols, width)).astype(np.float32)
+    rp, ci, v, perm = _csr_np(a)
+    return a, b, rp, ci, v, perm, rng
+
+
+@pytest.mark.parametrize("width", [1, 3, 7, 16, 60, 64, 100, 128, 256, 260, 512])
+@pytest.mark.parametrize("shape", [
+    (1, 1, 1), (50, 40, 0), (300, 200, 511), (300, 200, 512), (300, 200, 513),
+    (2000, 1500, 30000), (20000, 20000, 90000),
+])
+def test_spmm_matches_oracle(env, shape, width):
+    n_rows, n_cols, nnz = shape
+    a, b, rp, ci, v, _, _ = _spmm_case(env, n_rows, n_cols, nnz, width)
+    got = env["ops"].spmm(a, env["torch"].from_numpy(b).to(env["dev"])).cpu().numpy()
+    ref64, mag = env["oracle"].spmm_csr_f64(rp, ci, v, b)
+    assert_close_to_f64(got, ref64, mag, what="spmm %s w=%d" % (shape, width))
+    ref32 = env["oracle"].spmm_csr(rp, ci, v, b)
+    assert rel_maxnorm(got, ref32) <= RTOL
+
+
+@pytest.mark.parametrize("width", [7, 16, 256])
+def test_spmm_hub_and_empty_rows(env, width):
+    """Rows far longer than a chunk (completed from partial sums), runs of empty
+    rows at the start, the end and across chunk boundaries."""
+    n = 5000
+    hub = [(17, 6000), (18, 1500), (4000, 3000)]
+    empty = list(range(0, 9)) + list(range(2000, 2600)) + list(range(4990, 5000))
+    a, b, rp, ci, v, _, _ = _spmm_case(env, n, n, 40000, width, hub=hub, empty=empty, seed=5)
+    assert np.diff(rp).max() > 4 * 512
+    got = env["ops"].spmm(a, env["torch"].from_numpy(b).to(env["dev"])).cpu().numpy()
+    ref64, mag = env["oracle"].spmm_csr_f64(rp, ci, v, b)
+    assert_close_to_f64(got, ref64, mag, what="hub w=%d" % width)
+    assert np.all(got[np.asarray(empty)] == 0.0)
+
+
+def test_spmm_vs_tf_order_coo(env):
+    """Against the TF-order restatement: nonzeros walked in tuple order."""
+    rng = np.random.RandomState(11)
+    rows, cols, vals = random_coo(rng, 900, 800, 20000)
+    vals = vals.astype(np.float32)
+    b = rng.standard_normal((800, 16)).astype(np.float32)
+    a = env["sparse"].Csr.from_coo(rows, cols, vals, (900, 800), env["dev"])
+    got = env["ops"].spmm(a, env["torch"].from_numpy(b).to(env["dev"])).cpu().numpy()
+    ref = env["oracle"].spmm_coo(rows, cols, vals, b, 900)
+    assert rel_maxnorm(got, ref) <= RTOL
+    # adjoint (backward) product through the exact transpose
+    g = rng.standard_normal((900, 16)).astype(np.float32)
+    got_t = env["ops"].spmm(a.transpose(), env["torch"].from_numpy(g).to(env["dev"])).cpu().numpy()
+    ref_t = env["oracle"].spmm_coo_adjoint(rows, cols, vals, g, 800)
+    assert rel_maxnorm(got_t, ref_t) <= RTOL
+
+
+@pytest.mark.parametrize("width", [16, 256])
+def test_spmm_dropout_mask_relu_alpha_beta(env, width):
+    torch = env["torch"]
+    a, b, rp, ci, v, perm, rng = _spmm_case(env, 1500, 1200, 25000, width, seed=9)
+    keep = 0.5
+    mask = (rng.random_sample(a.nnz) < keep).astype(np.uint8)          # tuple order
+    v_drop = env["oracle"].sparse_dropout(v, mask[perm], keep)        # CSR order
+    bt = torch.from_numpy(b).to(env["dev"])
+    mt = torch.from_numpy(mask).to(env["dev"])
+    got = env["ops"].spmm(a, bt, mask=mt, mask_scale=1.0 / keep, relu=True).cpu().numpy()
+    ref64, mag = env["oracle"].spmm_csr_f64(rp, ci, v_drop, b)
+    assert_close_to_f64(got, np.maximum(ref64, 0.0), mag, what="mask+relu")
+    # the transposed product reuses the same tuple-order mask
+    g = rng.standard_normal((1500, width)).astype(np.float32)
+    t = a.transpose()
+    got_t = env["ops"].spmm(t, torch.from_numpy(g).to(env["dev"]), mask=mt, mask_scale=1.0 / keep).cpu().numpy()
+    trp, tci, tv, tperm = env["oracle"].csr_transpose(rp, ci, v_drop, 1200)
+    ref64_t, mag_t = env["oracle"].spmm_csr_f64(trp, tci, tv, g)
+    assert_close_to_f64(got_t, ref64_t, mag_t, what="mask transposed")
+    # alpha / beta
+    c0 = rng.standard_normal((1500, width)).astype(np.float32)
+    out = torch.from_numpy(c0.copy()).to(env["dev"])
+    env["ops"].spmm(a, bt, out=out, alpha=0.5, beta=-2.0)
+    ref64, mag = env["oracle"].spmm_csr_f64(rp, ci, v, b)
+    assert_close_to_f64(out.cpu().numpy(), 0.5 * ref64 - 2.0 * c0, 0.5 * mag + 2.0 * np.abs(c0), what="alpha/beta")
+
+
+def test_spmm_reproducible_and_strided(env):
+    torch = env["torch"]
+    a, b, rp, ci, v, _, _ = _spmm_case(env, 3000, 3000, 60000, 64, hub=[(5, 5000)], seed=2)
+    big = torch.zeros((3000, 200), device=env["dev"])
+    big[:, 8:72] = torch.from_numpy(b).to(env["dev"])
+    bview = big[:, 8:72]                      # ldb = 200, 32-byte aligned start
+    o1 = env["ops"].spmm(a, bview).cpu().numpy()
+    o2 = env["ops"].spmm(a, bview).cpu().numpy()
+    assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32))
+    o3 = env["ops"].spmm(a, torch.from_numpy(b).to(env["dev"])).cpu().numpy()
+    assert np.array_equal(o1.view(np.uint32), o3.view(np.uint32))
+    bodd = big[:, 9:73]                       # misaligned start -> scalar path
+    bodd.copy_(torch.from_numpy(b).to(env["dev"]))
+    o4 = env["ops"].spmm(a, bodd).cpu().numpy()
+    ref64, mag = env["oracle"].spmm_csr_f64(rp, ci, v, b)
+    assert_close_to_f64(o4, ref64, mag, what="misaligned")
+
+
+# ------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb,M,N,K", [
+    (0, 0, 1, 1, 1), (0, 0, 2708, 7, 16), (0, 0, 1000, 16, 1433), (0, 0, 4096, 256, 256),
+    (0, 0, 700, 128, 64), (0, 0, 513, 100, 37), (0, 1, 2708, 16, 7), (0, 1, 3000, 256, 16),
+    (1, 0, 16, 7, 2708), (1, 0, 256, 16, 100000), (1, 0, 256, 256, 20000), (1, 1, 33, 21, 65),
+])
+def test_gemm_matches_oracle(env, ta, tb, M, N, K):
+    torch = env["torch"]
+    rng = np.random.RandomState(M + N + K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    got = env["ops"].gemm(torch.from_numpy(a).to(env["dev"]), torch.from_numpy(b).to(env["dev"]),
+                          trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
+    ref64 = env["oracle"].gemm_f64(a, b, bool(ta), bool(tb))
+    mag = env["oracle"].gemm_f64(np.abs(a), np.abs(b), bool(ta), bool(tb))
+    assert_close_to_f64(got, ref64, mag, what="gemm %s" % ((ta, tb, M, N, K),))
+
+
+def test_gemm_mfma_layout_asymmetric(env):
+    """A = I against an asymmetric B catches a swapped accumulator row/col map."""
+    torch = env["torch"]
+    M = K = 512
+    N = 256
+    a = np.eye(M, K, dtype=np.float32)
+    b = (np.arange(K * N, dtype=np.float32).reshape(K, N) % 1021) - 400.0
+    got = env["ops"].gemm(torch.from_numpy(a).to(env["dev"]), torch.from_numpy(b).to(env["dev"])).cpu().numpy()
+    assert np.array_equal(got, b)
+    got = env["ops"].gemm(torch.from_numpy(a).to(env["dev"]), torch.from_numpy(b).to(env["dev"]),
+                          alpha=2.0, relu=True).cpu().numpy()
+    assert np.array_equal(got, np.maximum(2.0 * b, 0.0))
+
+
+# ----------------------------------------------------------------- glue kernels
+@pytest.mark.parametrize("n,c", [(1, 2), (2708, 7), (3327, 6), (100000, 16), (70000, 3)])
+def test_masked_softmax_xent(env, n, c):
+    torch = env["torch"]
+    rng = np.random.RandomState(n + c)
+    logits = (rng.standard_normal((n, c)) * 3).astype(np.float32)
+    labels = np.eye(c, dtype=np.float32)[rng.randint(0, c, size=n)]
+    mask = (rng.random_sample(n) < 0.3).astype(np.uint8)
+    mask[0] = 1
+    out, grad = env["ops"].masked_softmax_xent(torch.from_numpy(logits).to(env["dev"]),
+                                               torch.from_numpy(labels).to(env["dev"]),
+                                               torch.from_numpy(mask).to(env["dev"]))
+    out = out.cpu().numpy()
+    loss_ref, grad_ref = env["oracle"].masked_softmax_xent(logits, labels, mask)
+    acc_ref = env["oracle"].masked_accuracy(logits, labels, mask)
+    assert abs(out[0] - loss_ref) <= 1e-5 * abs(loss_ref) + 1e-7
+    assert abs(out[1] - acc_ref) <= 1e-6
+    g = grad.cpu().numpy()
+    assert np.abs(g - grad_ref).max() <= 1e-5 * np.abs(grad_ref).max() + 1e-12
+    assert np.all(g[mask == 0] == 0.0)
+
+
+def test_bernoulli_mask_bit_exact(env):
+    for n, keep, seed, off in [(1, 0.5, 1, 0), (1003, 0.5, 123, 0), (4097, 0.9, 7, 13), (50000, 0.25, 2 ** 40 + 5, 10 ** 12 + 3)]:
+        got = env["ops"].bernoulli_mask(n, keep, seed, off, env["dev"]).cpu().numpy()
+        ref = env["oracle"].bernoulli_mask(n, keep, seed, off)
+        assert np.array_equal(got, ref), (n, keep, seed, off)
+    m = env["ops"].bernoulli_mask(1 << 20, 0.5, 99, 0, env["dev"]).float().mean().item()
+    assert abs(m - 0.5) < 5e-3
+
+
+def test_dropout_relu_bwd_adam(env):
+    torch = env["torch"]
+    rng = np.random.RandomState(4)
+    for n in (1, 5, 1027, 100003):
+        x = rng.standard_normal(n).astype(np.float32)
+        dy = rng.standard_normal(n).astype(np.float32)
+        mask = (rng.random_sample(n) < 0.5).astype(np.uint8)
+        xt, dyt, mt = (torch.from_numpy(t).to(env["dev"]) for t in (x, dy, mask))
+        got = env["ops"].dropout_dense(xt, mt, 2.0).cpu().numpy()
+        assert np.array_equal(got, np.where(mask != 0, x * np.float32(2.0), np.float32(0)))
+        y = np.maximum(x, 0)
+        got = env["ops"].relu_dropout_bwd(torch.from_numpy(y).to(env["dev"]), dyt, mt, 2.0).cpu().numpy()
+        assert np.array_equal(got, np.where((y > 0) & (mask != 0), dy * np.float32(2.0), np.float32(0)))
+        got = env["ops"].relu_dropout_bwd(torch.from_numpy(y).to(env["dev"]), dyt).cpu().numpy()
+        assert np.array_equal(got, np.where(y > 0, dy, np.float32(0)))
+    # Adam, 3 steps, with weight decay folded into the gradient
+    n = 1433 * 16
+    w = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    wt, mt_, vt = (torch.from_numpy(t.copy()).to(env["dev"]) for t in (w, m, v))
+    for t in (1, 2, 3):
+        g = rng.standard_normal(n).astype(np.float32) * 0.01
+        env["ops"].adam_step(wt, torch.from_numpy(g).to(env["dev"]), mt_, vt, 0.01, t, weight_decay=5e-4)
+        env["oracle"].adam_step(w, (g + np.float32(5e-4) * w).astype(np.float32), m, v, 0.01, t)
+    assert np.abs(wt.cpu().numpy() - w).max() <= 1e-6
+    assert np.abs(mt_.cpu().numpy() - m).max() <= 1e-7
