@@ -1,0 +1,33 @@
+"""Masked loss / accuracy with the reference's names (reference gcn/metrics.py).
+Both are computed by one fused HIP kernel; the two nodes share its result."""
+from . import ops
+from . import tfcompat as tf
+
+
+def _loss_and_acc(preds, labels, mask):
+    def fn(run, z, y, m):
+        return ops.masked_softmax_xent_autograd(z, y, m)
+    return tf.Node(fn, (preds, labels, mask))
+
+
+_PAIRS = {}
+
+
+def _pair(preds, labels, mask):
+    key = (id(preds), id(labels), id(mask))
+    hit = _PAIRS.get(key)
+    if hit is None or hit[0] is not preds:
+        hit = (preds, _loss_and_acc(preds, labels, mask))
+        _PAIRS[key] = hit
+    return hit[1]
+
+
+def masked_softmax_cross_entropy(preds, labels, mask):
+    """mean_i(CE_i * mask_i / mean(mask)) over all rows
+    (reference gcn/metrics.py:4-10)."""
+    return tf.Node(lambda run, pair: pair[0], (_pair(preds, labels, mask),))
+
+
+def masked_accuracy(preds, labels, mask):
+    """Masked mean of argmax equality (reference gcn/metrics.py:13-20)."""
+    return tf.Node(lambda run, pair: pair[1], (_pair(preds, labels, mask),))

@@ -117,21 +117,30 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
 
 class _GemmFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
-        ctx.save_for_backward(a, b)
-        return gemm(a, b)
+    def forward(ctx, a, b, relu):
+        y = gemm(a, b, relu=relu)
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(a, b, y)
+        else:
+            ctx.save_for_backward(a, b)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, b = ctx.saved_tensors
         dy = dy.contiguous()
+        if ctx.relu:
+            a, b, y = ctx.saved_tensors
+            dy = relu_dropout_bwd(y, dy)
+        else:
+            a, b = ctx.saved_tensors
         da = gemm(dy, b, trans_b=True) if ctx.needs_input_grad[0] else None
         db = gemm(a, dy, trans_a=True) if ctx.needs_input_grad[1] else None
-        return da, db
+        return da, db, None
 
 
-def gemm_autograd(a, b):
-    return _GemmFn.apply(a, b)
+def gemm_autograd(a, b, relu=False):
+    return _GemmFn.apply(a, b, relu)
 
 
 # ------------------------------------------------------------- loss / accuracy

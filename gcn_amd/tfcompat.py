@@ -1,0 +1,552 @@
+"""The slice of the TensorFlow-1.x surface that the reference's ``gcn`` package
+and train scripts touch (gcn/layers.py, gcn/models.py, gcn/metrics.py,
+gcn/inits.py, gcn/train_normal.py), re-hosted on the HIP kernels.
+
+It keeps the reference's execution model -- build a graph of symbolic tensors
+once from a ``placeholders`` dict, then ``sess.run(fetches, feed_dict)`` -- so a
+train script written against the reference runs unchanged with
+``import gcn_amd.tfcompat as tf``.  A symbolic tensor is a :class:`Node`; a run
+evaluates the fetched nodes eagerly on the GPU, recording a torch autograd tape
+when an optimizer step is among the fetches.  Sparse tuples in the feed are
+turned into device CSR once and cached (the reference re-feeds them every step,
+gcn/utils.py:143-144).
+
+Only what the reference uses is provided; anything else raises AttributeError.
+"""
+import argparse
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ops
+from .sparse import Csr
+
+float32 = "float32"
+int32 = "int32"
+int64 = "int64"
+bool_ = "bool"
+
+_DEVICE = None
+
+
+def device():
+    """The GPU this process computes on (``cuda:LOCAL_RANK``).  Raises when no
+    GPU is visible: there is no CPU execution path."""
+    global _DEVICE
+    if _DEVICE is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("gcn_amd needs an AMD GPU (none visible); there is no CPU path")
+        _DEVICE = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(_DEVICE)
+    return _DEVICE
+
+
+# --------------------------------------------------------------------- flags
+class _FlagValues(object):
+    """Process-global flag registry (``tf.app.flags.FLAGS``): defined by the
+    entry script, read inside the library (reference gcn/models.py:95,102,114,
+    142,149,162).  Parsed from ``sys.argv`` on first attribute access."""
+
+    def __init__(self):
+        object.__setattr__(self, "_defs", {})
+        object.__setattr__(self, "_values", {})
+        object.__setattr__(self, "_parsed", False)
+
+    def _define(self, name, default, help_, typ):
+        self._defs[name] = (default, help_, typ)
+        self._values[name] = default
+        object.__setattr__(self, "_parsed", False)
+
+    def _parse(self, argv=None):
+        ap = argparse.ArgumentParser(add_help=False)
+        for name, (default, help_, typ) in self._defs.items():
+            ap.add_argument("--" + name, type=typ, default=self._values[name], help=help_)
+        ns, _ = ap.parse_known_args(sys.argv[1:] if argv is None else argv)
+        self._values.update(vars(ns))
+        object.__setattr__(self, "_parsed", True)
+
+    def __getattr__(self, name):
+        if name not in self._defs:
+            raise AttributeError("flag %r is not defined" % name)
+        if not self._parsed:
+            self._parse()
+        return self._values[name]
+
+    def __setattr__(self, name, value):
+        if name not in self._defs:
+            raise AttributeError("flag %r is not defined" % name)
+        self._values[name] = value
+
+    def __contains__(self, name):
+        return name in self._defs
+
+
+def _str2bool(s):
+    return str(s).lower() in ("1", "true", "t", "yes", "y")
+
+
+class _Flags(object):
+    FLAGS = _FlagValues()
+
+    def DEFINE_string(self, name, default, help_=""):
+        self.FLAGS._define(name, default, help_, str)
+
+    def DEFINE_float(self, name, default, help_=""):
+        self.FLAGS._define(name, default, help_, float)
+
+    def DEFINE_integer(self, name, default, help_=""):
+        self.FLAGS._define(name, default, help_, int)
+
+    def DEFINE_boolean(self, name, default, help_=""):
+        self.FLAGS._define(name, default, help_, _str2bool)
+
+    DEFINE_bool = DEFINE_boolean
+
+
+class _App(object):
+    flags = _Flags()
+
+
+app = _App()
+flags = app.flags
+
+
+# ---------------------------------------------------------------- graph nodes
+class Node(object):
+    """Symbolic tensor: ``fn(run, *evaluated inputs)`` computes its value."""
+
+    def __init__(self, fn, inputs=(), name=None, static_shape=None):
+        self.fn = fn
+        self.inputs = tuple(inputs)
+        self.name = name
+        self.static_shape = static_shape
+
+    def get_shape(self):
+        return _Shape(self.static_shape)
+
+    # scalar arithmetic used when the loss is assembled (gcn/models.py:146-153)
+    def __add__(self, other):
+        return Node(lambda run, a, b: a + b, (self, other))
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        return Node(lambda run, a, b: a * b, (self, other))
+
+    __rmul__ = __mul__
+
+    def __hash__(self):
+        return id(self)
+
+    def __eq__(self, other):
+        return self is other
+
+
+class _Shape(object):
+    def __init__(self, shape):
+        self._shape = shape
+
+    def as_list(self):
+        if self._shape is None:
+            raise ValueError("shape is unknown")
+        return list(self._shape)
+
+
+class Placeholder(Node):
+    def __init__(self, dtype, shape=None, default=None, sparse=False, name=None):
+        super(Placeholder, self).__init__(None, (), name, tuple(shape) if shape is not None else None)
+        self.dtype = dtype
+        self.default = default
+        self.sparse = sparse
+
+
+def placeholder(dtype, shape=None, name=None):
+    return Placeholder(dtype, shape, name=name)
+
+
+def placeholder_with_default(input, shape, name=None):
+    return Placeholder(float32, shape, default=input, name=name)
+
+
+def sparse_placeholder(dtype, shape=None, name=None):
+    if isinstance(shape, Node):
+        shape = None
+    return Placeholder(dtype, shape, sparse=True, name=name)
+
+
+def constant(value, dtype=None, name=None):
+    return np.asarray(value)
+
+
+class SparseValue(object):
+    """A fed sparse tensor on the device, with an optional pending dropout mask
+    (``sparse_dropout`` does not compact: dropped entries are zeroed inside the
+    product that consumes the tensor)."""
+
+    def __init__(self, csr, mask=None, scale=1.0, source=None):
+        self.csr = csr
+        self.mask = mask
+        self.scale = scale
+        self.source = source  # the host tuple it was fed as
+
+
+# ------------------------------------------------------------------ variables
+_GLOBAL_VARIABLES = []
+_SCOPE = []
+_SEED = [None]
+_RNG_CALLS = [0]
+
+
+class GraphKeys(object):
+    GLOBAL_VARIABLES = "variables"
+
+
+class Variable(Node):
+    """Trainable fp32 tensor, materialised on the device by
+    ``global_variables_initializer``; ``initial`` is a callable returning a numpy
+    array (so that parity runs can inject weights with :meth:`load`)."""
+
+    def __init__(self, initial, name=None):
+        super(Variable, self).__init__(None, (), None)
+        scope = "/".join(_SCOPE)
+        self.name = (scope + "/" if scope else "") + (name or "Variable") + ":0"
+        self._initial = initial
+        self.tensor = None
+        self.adam_m = None
+        self.adam_v = None
+        arr = initial() if callable(initial) else np.asarray(initial)
+        self._init_value = np.ascontiguousarray(arr, dtype=np.float32)
+        self.static_shape = self._init_value.shape
+        _GLOBAL_VARIABLES.append(self)
+
+    def initialize(self):
+        self.tensor = torch.from_numpy(self._init_value.copy()).to(device()).requires_grad_(True)
+        self.adam_m = torch.zeros_like(self.tensor, requires_grad=False)
+        self.adam_v = torch.zeros_like(self.tensor, requires_grad=False)
+
+    def load(self, value, sess=None):
+        """Overwrite the value (resets the Adam moments)."""
+        self._init_value = np.ascontiguousarray(value, dtype=np.float32).reshape(self._init_value.shape)
+        self.initialize()
+
+    def numpy(self):
+        return self.tensor.detach().cpu().numpy()
+
+
+def get_collection(key, scope=None):
+    if key != GraphKeys.GLOBAL_VARIABLES:
+        return []
+    if scope is None:
+        return list(_GLOBAL_VARIABLES)
+    return [v for v in _GLOBAL_VARIABLES if v.name.startswith(scope + "/") or v.name.startswith(scope)]
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    _SCOPE.append(name)
+    try:
+        yield
+    finally:
+        _SCOPE.pop()
+
+
+@contextlib.contextmanager
+def name_scope(name):
+    yield
+
+
+def set_random_seed(seed):
+    _SEED[0] = int(seed)
+    _RNG_CALLS[0] = 0
+
+
+def _next_seed():
+    """A fresh Philox key per random op instance, derived from the graph seed."""
+    _RNG_CALLS[0] += 1
+    base = _SEED[0] if _SEED[0] is not None else int.from_bytes(os.urandom(4), "little")
+    return (base * 1000003 + _RNG_CALLS[0]) & (2 ** 63 - 1)
+
+
+def random_uniform(shape, minval=0.0, maxval=1.0, dtype=float32, seed=None):
+    """Initialiser form only (reference gcn/inits.py:7,14): returns a callable
+    drawing the array on the host.  TensorFlow's own random stream cannot be
+    reproduced; parity runs inject weights instead."""
+    s = _next_seed()
+
+    def draw():
+        rng = np.random.RandomState(s % (2 ** 32))
+        return rng.uniform(minval, maxval, size=tuple(int(d) for d in shape)).astype(np.float32)
+    return draw
+
+
+def zeros(shape, dtype=float32):
+    return lambda: np.zeros(tuple(int(d) for d in shape), dtype=np.float32)
+
+
+def ones(shape, dtype=float32):
+    return lambda: np.ones(tuple(int(d) for d in shape), dtype=np.float32)
+
+
+def global_variables_initializer():
+    def init(run):
+        for v in _GLOBAL_VARIABLES:
+            if v.tensor is None:
+                v.initialize()
+        return None
+    return Node(init, (), "init")
+
+
+def reset_default_graph():
+    del _GLOBAL_VARIABLES[:]
+    del _SCOPE[:]
+
+
+# ------------------------------------------------------------------------ ops
+def _is_sparse(v):
+    return isinstance(v, SparseValue)
+
+
+def sparse_tensor_dense_matmul(sp_a, b):
+    def fn(run, a, bb):
+        if not _is_sparse(a):
+            raise TypeError("sparse_tensor_dense_matmul: first operand must be sparse")
+        return ops.spmm_autograd(a.csr, bb.contiguous(), a.mask, a.scale)
+    return Node(fn, (sp_a, b))
+
+
+def matmul(a, b):
+    return Node(lambda run, x, y: ops.gemm_autograd(x.contiguous(), y.contiguous()), (a, b))
+
+
+def sparse_retain_scaled(x, keep_prob, seed_key):
+    """sparse_retain(x, floor(keep + U)) * (1/keep) as one lazy step
+    (reference gcn/layers.py:21-27)."""
+    def fn(run, xv, keep):
+        keep = float(keep)
+        if keep >= 1.0:
+            return xv
+        if xv.mask is not None:
+            raise NotImplementedError("sparse dropout applied twice to one tensor")
+        mask = run.dropout_mask(seed_key, xv.csr.nnz, keep)
+        return SparseValue(xv.csr, mask, xv.scale / keep, xv.source)
+    return Node(fn, (x, keep_prob))
+
+
+class _NN(object):
+    @staticmethod
+    def relu(x):
+        return Node(lambda run, v: torch.relu(v), (x,)) if isinstance(x, Node) else torch.relu(x)
+
+    @staticmethod
+    def dropout(x, keep_prob, seed_key=None):
+        key = seed_key if seed_key is not None else _next_seed()
+
+        def fn(run, v, keep):
+            keep = float(keep)
+            if keep >= 1.0:
+                return v
+            mask = run.dropout_mask(key, v.numel(), keep)
+            return ops.dropout_dense_autograd(v, mask, 1.0 / keep)
+        return Node(fn, (x, keep_prob))
+
+    @staticmethod
+    def softmax(x):
+        return Node(lambda run, v: torch.softmax(v, dim=1), (x,))
+
+    @staticmethod
+    def l2_loss(var):
+        return Node(lambda run, v: (v * v).sum() * 0.5, (var,))
+
+    @staticmethod
+    def softmax_cross_entropy_with_logits(logits=None, labels=None):
+        raise NotImplementedError("use gcn_amd.metrics.masked_softmax_cross_entropy")
+
+
+nn = _NN()
+
+
+def add_n(xs):
+    xs = list(xs)
+    if len(xs) == 1:
+        return xs[0]
+
+    def fn(run, *vs):
+        out = vs[0]
+        for v in vs[1:]:
+            out = out + v
+        return out
+    return Node(fn, xs)
+
+
+class _Summary(object):
+    @staticmethod
+    def histogram(name, value):
+        return None
+
+
+summary = _Summary()
+
+
+# ------------------------------------------------------------------ optimizer
+class _OptOp(Node):
+    def __init__(self, optimizer, loss):
+        super(_OptOp, self).__init__(None, (), "opt_op")
+        self.optimizer = optimizer
+        self.loss = loss
+
+
+class AdamOptimizer(object):
+    """tf.train.AdamOptimizer with TF's defaults and update rule
+    (reference gcn/models.py:142): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+    w -= lr_t * m / (sqrt(v) + eps)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.learning_rate = learning_rate
+        self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
+        self.step = 0
+
+    def minimize(self, loss):
+        return _OptOp(self, loss)
+
+    def apply(self, variables, grads):
+        self.step += 1
+        for v, g in zip(variables, grads):
+            if g is None:
+                continue
+            with torch.no_grad():
+                ops.adam_step(v.tensor, g.contiguous(), v.adam_m, v.adam_v, self.learning_rate,
+                              self.step, self.beta1, self.beta2, self.epsilon)
+
+
+class _Saver(object):
+    def __init__(self, var_dict):
+        self.vars = dict(var_dict) if isinstance(var_dict, dict) else {v.name: v for v in var_dict}
+
+    def save(self, sess, path):
+        d = os.path.dirname(path)
+        if d and not os.path.isdir(d):
+            os.makedirs(d)
+        torch.save({k: v.tensor.detach().cpu() for k, v in self.vars.items()}, path)
+        return path
+
+    def restore(self, sess, path):
+        state = torch.load(path, weights_only=True)
+        for k, v in self.vars.items():
+            v.load(state[k].numpy())
+
+
+class _Train(object):
+    AdamOptimizer = AdamOptimizer
+    Saver = _Saver
+
+
+train = _Train()
+
+
+# -------------------------------------------------------------------- session
+class _Run(object):
+    """State of one ``sess.run``: feed values, memo, dropout masks."""
+
+    def __init__(self, sess, feed):
+        self.sess = sess
+        self.feed = feed
+        self.memo = {}
+
+    def dropout_mask(self, key, n, keep):
+        provider = self.sess.mask_provider
+        if provider is not None:
+            m = provider(key, n, keep)
+            if m is not None:
+                return torch.as_tensor(np.ascontiguousarray(m, dtype=np.uint8)).to(device())
+        return ops.bernoulli_mask(n, keep, key, self.sess.run_counter * (2 ** 40), device())
+
+    def value(self, node):
+        if not isinstance(node, Node):
+            return node
+        if node in self.memo:
+            return self.memo[node]
+        if isinstance(node, Placeholder):
+            if node in self.feed:
+                v = self.sess.to_device(node, self.feed[node])
+            elif node.default is not None:
+                v = node.default
+            else:
+                raise ValueError("placeholder %r was not fed" % (node.name,))
+        elif isinstance(node, Variable):
+            if node.tensor is None:
+                raise RuntimeError("variable %s is not initialised" % node.name)
+            v = node.tensor
+        else:
+            v = node.fn(self, *[self.value(i) for i in node.inputs])
+        self.memo[node] = v
+        return v
+
+
+class Session(object):
+    def __init__(self, config=None):
+        self._cache = {}
+        self.run_counter = 0
+        # hook: mask_provider(key, n, keep) -> uint8 array or None; lets a
+        # parity run share dropout masks with the oracle
+        self.mask_provider = None
+
+    def to_device(self, ph, value):
+        """Upload a fed value once; later feeds of the same object reuse it."""
+        if isinstance(value, (SparseValue, torch.Tensor)):
+            return value
+        key = id(value)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] is value:
+            return hit[1]
+        if ph.sparse:
+            out = SparseValue(Csr.from_tuple(value, device()), source=value)
+        elif isinstance(value, (tuple, list, int, float)):
+            out = value  # e.g. num_features_nonzero = (nnz,), dropout = 0.5
+        else:
+            arr = np.asarray(value)
+            if arr.ndim == 0:
+                out = arr[()].item()
+            elif arr.dtype == np.bool_ or np.issubdtype(arr.dtype, np.integer):
+                out = torch.from_numpy(np.ascontiguousarray(arr != 0).astype(np.uint8)).to(device())
+            else:
+                out = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device())
+        self._cache[key] = (value, out)
+        return out
+
+    def run(self, fetches, feed_dict=None, options=None, run_metadata=None):
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        device()
+        self.run_counter += 1
+        run = _Run(self, feed_dict or {})
+        opt_ops = [f for f in flist if isinstance(f, _OptOp)]
+        results = [None] * len(flist)
+        with torch.set_grad_enabled(bool(opt_ops)):
+            for i, f in enumerate(flist):
+                if not isinstance(f, _OptOp):
+                    results[i] = run.value(f)
+            for op in opt_ops:
+                loss = run.value(op.loss)
+                variables = [v for v in _GLOBAL_VARIABLES if v.tensor is not None]
+                grads = torch.autograd.grad(loss, [v.tensor for v in variables], allow_unused=True)
+                op.optimizer.apply(variables, grads)
+        out = []
+        for r in results:
+            if isinstance(r, torch.Tensor):
+                r = r.detach().cpu().numpy()
+                if r.ndim == 0:
+                    r = r[()]
+            out.append(r)
+        return out[0] if single else out
+
+    def close(self):
+        self._cache.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -1,0 +1,46 @@
+"""Micro-benchmark of the SpMM kernel on an RMAT graph (development tool)."""
+import argparse
+import sys
+import os
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from gcn_amd import ops, rmat
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--edge-factor", type=int, default=8)
+    ap.add_argument("--width", type=int, nargs="+", default=[256])
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    a = rmat.rmat_ahat(args.scale, args.edge_factor, 123, dev)
+    torch.cuda.synchronize()
+    print("graph: n=%d nnz=%d max_deg=%d build %.2fs" % (
+        a.n_rows, a.nnz, int((a.row_ptr[1:] - a.row_ptr[:-1]).max()), time.time() - t0), flush=True)
+    for w in args.width:
+        b = torch.rand((a.n_cols, w), device=dev) * 2 - 1
+        out = torch.empty((a.n_rows, w), device=dev)
+        ops.spmm(a, b, out=out)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+        ev[0].record()
+        for i in range(args.iters):
+            ops.spmm(a, b, out=out)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
+        med = ms[len(ms) // 2]
+        algo = a.nnz * (8 + 4 * w) + a.n_rows * 4 * w + 8 * (a.n_rows + 1)
+        print("W=%d: %.3f ms (min %.3f)  nnz*F/s=%.3e  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)" % (
+            w, med, ms[0], a.nnz * w / (med * 1e-3), algo / (med * 1e-3) / 1e9,
+            algo / (med * 1e-3) / 8e12 * 100), flush=True)
+        del b, out
+
+
+if __name__ == "__main__":
+    main()
