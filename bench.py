@@ -1,0 +1,261 @@
+"""Headline benchmark: full-batch two-layer GCN training steps on a synthetic
+RMAT graph (BASELINE.json config "RMAT 2^24 nodes, avg degree 16, F=256, hidden
+256 full-batch GCN on one MI355X"; with N GPUs the graph grows to
+2^(24+log2 N) nodes, row-partitioned, fixed 2^24 rows per GPU = weak scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one optimisation step = one epoch of the full-batch model: forward
+(dropout, X W1, A_hat P1 + relu, dropout, H W2, A_hat P2), masked loss,
+backward (A_hat^T dZ, H'^T dP2, dP2 W2^T, A_hat^T dH, X'^T dP1) and Adam, with
+every input resident in HBM.  Rank 0 prints ONE JSON line.  `value` is the
+SpMM work of the whole job per second, in nnz*F/s: (nnz(A_hat) * sum of the
+widths of the four SpMM of a step) * steps / time.  `roofline` is the dominant
+kernel (the F=256 SpMM) timed alone with HIP events inside the timed region;
+`cpu_baseline` is the oracle's restatement of the TensorFlow CPU SpMM timed on
+a bounded slice of the same matrix.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E (spec)
+
+
+def algorithmic_bytes(nnz, n_rows, width):
+    """No-reuse gather model of one SpMM: every nonzero reads its column index,
+    its value and one row of the dense operand; every output row is written
+    once; row_ptr is read once."""
+    return nnz * (4 + 4 + 4 * width) + n_rows * 4 * width + 8 * (n_rows + 1)
+
+
+def cpu_baseline(a, b_dev, rows, width):
+    """Oracle SpMM (TensorFlow CPU order, one thread; then OpenMP over rows) on
+    the first `rows` rows of the same matrix against the same dense operand."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    rp = a.row_ptr[:rows + 1].cpu().numpy()
+    nnz = int(rp[-1])
+    ci = a.col_idx[:nnz].cpu().numpy()
+    v = a.val[:nnz].cpu().numpy()
+    b = b_dev.cpu().numpy()
+    r = np.repeat(np.arange(rows, dtype=np.int32), np.diff(rp)).astype(np.int32)
+    t0 = time.perf_counter()
+    oracle.spmm_coo(r, ci, v, b, rows)
+    t1 = time.perf_counter()
+    oracle.spmm_csr(rp, ci, v, b, omp=True)
+    t2 = time.perf_counter()
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": nnz * width / (t1 - t0), "unit": "nnz*F/s", "cores": 1, "kind": "port",
+        "sample": "rows [0,%d) of the same A_hat (nnz %d) x the same [N,%d] fp32 operand, "
+                  "nonzeros walked in row-major tuple order, single thread" % (rows, nnz, width),
+        "seconds": t1 - t0,
+        "all_cores": {"value": nnz * width / (t2 - t1), "cores": oracle.max_threads(),
+                      "seconds": t2 - t1, "kind": "port (OpenMP over rows)"},
+        "host_cpu": model, "host_cpu_count": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=0, help="log2 of the node count (default 24 + log2 gpus)")
+    ap.add_argument("--edge-factor", type=int, default=8, help="undirected edges per node (avg degree = 2x)")
+    ap.add_argument("--features", type=int, default=256)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=16)
+    ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU-baseline slice (0 = skip)")
+    ap.add_argument("--slab-cols", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gcn_amd import engine, ops, rmat
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if world & (world - 1):
+        raise SystemExit("the number of GPUs must be a power of two")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    scale = args.scale or (24 + int(math.log2(world)))
+    n = 1 << scale
+    n_loc = n // world
+    rb, re_ = rank * n_loc, (rank + 1) * n_loc
+    seed = 123
+
+    # ---- inputs, generated on the device (synthetic; the reference's seed) ----
+    def gather_degrees(local):
+        if world == 1:
+            return local
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+
+    t_build = time.time()
+    a = rmat.rmat_ahat(scale, args.edge_factor, seed, dev, rb, re_, gather_degrees if world > 1 else None)
+    nnz_t = torch.tensor([a.nnz], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(nnz_t, group=group)
+    nnz_global = int(nnz_t.item())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(124 + rank)
+    x = torch.empty((n_loc, args.features), dtype=torch.float32, device=dev)
+    x.uniform_(-1.0, 1.0, generator=gen)
+    gw = torch.Generator(device=dev)
+    gw.manual_seed(125)  # same weights on every rank
+    r1 = math.sqrt(6.0 / (args.features + args.hidden))
+    r2 = math.sqrt(6.0 / (args.hidden + args.classes))
+    w1 = (torch.rand((args.features, args.hidden), device=dev, generator=gw) * 2 - 1) * r1
+    w2 = (torch.rand((args.hidden, args.classes), device=dev, generator=gw) * 2 - 1) * r2
+    gl = torch.Generator(device=dev)
+    gl.manual_seed(126 + rank)
+    cls = torch.randint(0, args.classes, (n_loc,), device=dev, generator=gl)
+    labels = torch.zeros((n_loc, args.classes), dtype=torch.float32, device=dev)
+    labels.scatter_(1, cls.view(-1, 1), 1.0)
+    lmask = torch.zeros(n_loc, dtype=torch.uint8, device=dev)
+    lmask[: max(1, n_loc // 100)] = 1          # 1 % of the nodes are labelled
+    mask_total = world * max(1, n_loc // 100)
+    del cls
+
+    model = engine.FullBatchGCN(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
+                                row_begin=rb, n_global=n, seed=seed, group=group, world_size=world,
+                                slab_cols=args.slab_cols or None)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    # ---- time the dominant kernel alone, inside the timed region -------------
+    n_ev = 2 * args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for s, e in ev:
+        s.record()
+        e.record()
+    ev_used = []
+    real_spmm = ops.spmm
+
+    class Timed(object):
+        """ops facade: wide SpMM launches of the timed steps get an event pair."""
+        armed = False
+
+        def __getattr__(self, name):
+            return getattr(ops, name)
+
+        def spmm(self, aa, b, **kw):
+            if Timed.armed and b.shape[1] == args.hidden and len(ev_used) < n_ev and (world == 1):
+                s, e = ev[len(ev_used)]
+                ops.profile_spmm_events(s, e)
+                out = real_spmm(aa, b, **kw)
+                ops.profile_spmm_events(None, None)
+                ev_used.append((s, e))
+                return out
+            return real_spmm(aa, b, **kw)
+
+    model.k = Timed()
+
+    def barrier():
+        if world > 1:
+            dist.barrier(group=group)
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step()
+    barrier()
+    Timed.armed = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    Timed.armed = False
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    dt = float(t.item())
+    loss_acc = out.cpu().tolist()
+
+    if rank == 0:
+        units = model.spmm_units_per_step(nnz_global)
+        result = {
+            "metric": "GCN SpMM nnz*F/s (full-batch epoch: fwd + bwd + Adam)",
+            "value": units * args.steps / dt,
+            "unit": "nnz*F/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "RMAT scale %d (2^%d nodes), avg degree %d, F=%d, hidden %d, %d classes, "
+                            "2-layer GCN, dropout 0.5, Adam" % (scale, scale, 2 * args.edge_factor,
+                                                                args.features, args.hidden, args.classes),
+                "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
+                "spmm_per_step": "2 x width %d + 2 x width %d" % (args.hidden, args.classes),
+            },
+            "epoch_ms": dt / args.steps * 1e3,
+            "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
+            "build_seconds": t_build,
+        }
+        if ev_used:
+            ms = [s.elapsed_time(e) for s, e in ev_used]
+            avg = sum(ms) / len(ms) * 1e-3
+            bytes_ = algorithmic_bytes(a.nnz, a.n_rows, args.hidden)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")) as fh:
+                    rec = json.load(fh)
+                if rec.get("scale") == scale and rec.get("width") == args.hidden and world == 1:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
+            result["roofline"] = {
+                "bound": "hbm", "kernel": "spmm_chunk_kernel<4,8> (A_hat x [N,%d] fp32)" % args.hidden,
+                "achieved": bytes_ / avg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_, "avg_launch_ms": avg * 1e3,
+                "launches_timed": len(ms), "kernel_nnzF_per_s": a.nnz * args.hidden / avg,
+                "compulsory_bytes_per_launch": 8 * a.nnz + 8 * a.n_rows * args.hidden + 8 * (a.n_rows + 1),
+            }
+        if args.cpu_rows and world == 1:
+            try:
+                b_dev = model.p1  # any resident [N, hidden] fp32 operand
+                result["cpu_baseline"] = cpu_baseline(a, b_dev, min(args.cpu_rows, a.n_rows), args.hidden)
+            except Exception as exc:  # the baseline is a side measurement; never lose the line
+                result["cpu_baseline"] = {"value": None, "unit": "nnz*F/s", "cores": 0, "kind": "port",
+                                          "sample": "failed: %r" % (exc,)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier(group=group)
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

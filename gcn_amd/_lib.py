@@ -48,13 +48,14 @@ SIGNATURES = {
     "gcnx_spmm_workspace_bytes": (_sz, [_i64, _i32]),
     "gcnx_spmm_csr_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32,
                                  _int, _p, _sz, _p]),
+    "gcnx_profile_spmm_events": (None, [_p, _p]),
     "gcnx_coo_interleave_supports": (_int, [_i32, _p, _p, _p, _i64, _p, _int, _p, _p, _p, _p]),
     "gcnx_gemm_workspace_bytes": (_sz, [_int, _int, _i64, _i64, _i64]),
     "gcnx_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _f32, _f32,
                              _int, _p, _sz, _p]),
     "gcnx_xent_workspace_bytes": (_sz, [_i64]),
-    "gcnx_masked_softmax_xent_f32": (_int, [_i64, _i32, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p,
-                                            _sz, _p]),
+    "gcnx_masked_softmax_xent_f32": (_int, [_i64, _i32, _p, _i64, _p, _i64, _p, _f64, _p, _p, _i64,
+                                            _p, _sz, _p]),
     "gcnx_dropout_dense_f32": (_int, [_i64, _p, _p, _f32, _p, _p]),
     "gcnx_bernoulli_mask_u8": (_int, [_i64, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),

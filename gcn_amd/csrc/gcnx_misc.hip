@@ -271,10 +271,13 @@ extern "C" size_t gcnx_xent_workspace_bytes(int64_t n) {
   return (size_t)(1 + 3 * (size_t)xent_blocks(n < 0 ? 0 : n)) * sizeof(double);
 }
 
+__global__ void set_double_kernel(double *dst, double v) { *dst = v; }
+
 extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const float *logits,
                                             int64_t ld, const float *labels, int64_t ldl,
-                                            const uint8_t *mask, float *out_loss_acc, float *grad,
-                                            int64_t ldg, void *ws, size_t ws_bytes, void *stream) {
+                                            const uint8_t *mask, double mask_total,
+                                            float *out_loss_acc, float *grad, int64_t ldg,
+                                            void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(n > 0 && n_class > 0 && logits && labels && mask && out_loss_acc,
                GCNX_ERR_INVALID_ARG, "xent: bad argument");
   GCNX_REQUIRE(ld >= n_class && ldl >= n_class && (!grad || ldg >= n_class), GCNX_ERR_INVALID_ARG,
@@ -285,8 +288,12 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
   const int nb = xent_blocks(n);
   double *w = static_cast<double *>(ws);
   double *msum = w, *cnt = w + 1, *lp = w + 1 + nb, *hp = w + 1 + 2 * nb;
-  hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(kBlock), 0, st, n, mask, cnt);
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, nb, cnt, msum);
+  if (mask_total > 0.0) {
+    hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, st, msum, mask_total);
+  } else {
+    hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(kBlock), 0, st, n, mask, cnt);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, nb, cnt, msum);
+  }
   hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
                      ldl, mask, msum, grad, ldg, lp, hp);
   hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, lp, hp, out_loss_acc);

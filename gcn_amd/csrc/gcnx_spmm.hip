@@ -250,6 +250,13 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 using namespace gcnx;
 
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
+extern "C" void gcnx_profile_spmm_events(void *start, void *stop) {
+  g_prof_start = static_cast<hipEvent_t>(start);
+  g_prof_stop = static_cast<hipEvent_t>(stop);
+}
+
 extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunk; }
 
 extern "C" int64_t gcnx_spmm_num_chunks(int64_t nnz) { return nnz <= 0 ? 0 : ceil_div(nnz, kChunk); }
@@ -327,16 +334,20 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
   const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
   if (v4) {
     const unsigned gy = (unsigned)ceil_div(width, kWave * 4);
+    if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
     hipLaunchKernelGGL((spmm_chunk_kernel<4, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     GCNX_CHECK_LAUNCH();
+    if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
     if (k.n_chunks > 1) {
       hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
       GCNX_CHECK_LAUNCH();
     }
   } else {
     const unsigned gy = (unsigned)ceil_div(width, kWave);
+    if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
     hipLaunchKernelGGL((spmm_chunk_kernel<1, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     GCNX_CHECK_LAUNCH();
+    if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
     if (k.n_chunks > 1) {
       hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
       GCNX_CHECK_LAUNCH();

@@ -1,0 +1,185 @@
+"""Full-batch two-layer GCN step for large graphs with DENSE input features,
+written out by hand (no autograd tape, buffers allocated once) and
+row-partitioned across the GPUs of one node.
+
+It computes exactly what the reference's ``GCN`` model computes for
+``sparse_inputs=False`` (gcn/models.py:159-174, gcn/layers.py:203-226,
+gcn/metrics.py:4-20, Adam per gcn/models.py:142):
+
+    X' = dropout(X)            P1 = X' W1        H  = relu(A_hat P1)
+    H' = dropout(H)            P2 = H' W2        Z  = A_hat P2
+    loss = wd * |W1|^2 / 2 + masked softmax cross-entropy(Z)
+
+and the backward products  A_hat^T dZ,  H'^T dP2,  dP2 W2^T,  A_hat^T dH,
+X'^T dP1.  With P ranks, rank p owns a contiguous block of rows of A_hat and of
+every activation; the dense operand of each SpMM is assembled by an all-gather
+of the row shards (RCCL over xGMI via torch.distributed), issued in column
+slabs on the communication stream so that the SpMM of slab s overlaps the
+transfer of slab s+1.  Weight gradients and the loss are all-reduced; Adam runs
+replicated.  Dropout masks are a pure function of (seed, step, global element
+index), so a run gives the same numbers for any GPU count.
+"""
+import math
+
+import torch
+
+from . import ops as _hip_ops
+
+
+class FullBatchGCN(object):
+    def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
+                 w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
+                 dropout=0.5, seed=123, group=None, world_size=1, slab_cols=None, kernels=None,
+                 keep_masks=False):
+        """``a_local``: Csr of the local rows of A_hat (global column ids);
+        ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
+        normalised adjacency of an undirected graph is bitwise symmetric).
+        ``w1`` [F, hidden], ``w2`` [hidden, n_class]: initial weights (device
+        tensors, identical on every rank).  ``mask_total``: number of labelled
+        rows over all ranks."""
+        self.k = kernels if kernels is not None else _hip_ops
+        self.a = a_local
+        self.at = a_bwd_local if a_bwd_local is not None else a_local
+        self.x = x_local
+        self.y = labels_local
+        self.ymask = mask_local
+        self.mask_total = float(mask_total)
+        self.n_loc, self.f = x_local.shape
+        self.h, self.c = int(n_hidden), int(n_class)
+        self.n = int(n_global if n_global is not None else a_local.n_cols)
+        self.row_begin = int(row_begin)
+        self.dev = x_local.device
+        self.lr, self.wd, self.keep = lr, weight_decay, 1.0 - dropout
+        self.seed = int(seed)
+        self.group, self.world = group, int(world_size)
+        self.step_no = 0
+        self.keep_masks = keep_masks
+        self.w1 = w1.clone().contiguous()
+        self.w2 = w2.clone().contiguous()
+        self.m1, self.v1 = torch.zeros_like(self.w1), torch.zeros_like(self.w1)
+        self.m2, self.v2 = torch.zeros_like(self.w2), torch.zeros_like(self.w2)
+        e = lambda *s, **kw: torch.empty(s, dtype=kw.get("dtype", torch.float32), device=self.dev)
+        nl = self.n_loc
+        # activations / gradients of the local rows, allocated once
+        self.xd = e(nl, self.f)        # dropout(X)
+        self.p1 = e(nl, self.h)        # X' W1; later dP2 W2^T (gradient wrt H')
+        self.hb = e(nl, self.h)        # relu(A P1); later A^T dH (gradient wrt P1)
+        self.hd = e(nl, self.h)        # dropout(H)
+        self.p2 = e(nl, self.c)
+        self.z = e(nl, self.c)
+        self.dz = e(nl, self.c)
+        self.dp2 = e(nl, self.c)
+        self.g1, self.g2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
+        self.mask1 = e(nl * self.f, dtype=torch.uint8) if self.keep < 1.0 else None
+        self.mask2 = e(nl * self.h, dtype=torch.uint8) if self.keep < 1.0 else None
+        # gather buffers (only with more than one rank)
+        if self.world > 1:
+            if slab_cols is None:
+                budget = 48 * (1 << 30)        # two slab buffers stay under this
+                slab_cols = self.h
+                while slab_cols > 16 and 2 * self.n * slab_cols * 4 > budget:
+                    slab_cols //= 2
+            self.slab = int(slab_cols)
+            self.gbuf = [e(self.n, self.slab), e(self.n, self.slab)]
+            self.pack = [e(nl, self.slab), e(nl, self.slab)]
+        else:
+            self.slab = None
+
+    # ------------------------------------------------------------ collectives
+    def _aggregate(self, a, src, dst, relu):
+        """dst = act(a @ gather_rows(src)); src, dst are [n_loc, W]."""
+        if self.world == 1:
+            self.k.spmm(a, src, out=dst, relu=relu)
+            return
+        import torch.distributed as dist
+        w = src.shape[1]
+        slab = min(self.slab, w)
+        starts = list(range(0, w, slab))
+        works = [None] * len(starts)
+
+        def launch(i):
+            c0 = starts[i]
+            nc = min(slab, w - c0)
+            pk = self.pack[i % 2][:, :nc] if nc == self.slab else self.pack[i % 2].view(-1)[:self.n_loc * nc].view(self.n_loc, nc)
+            gb = self.gbuf[i % 2] if nc == self.slab else self.gbuf[i % 2].view(-1)[:self.n * nc].view(self.n, nc)
+            pk.copy_(src[:, c0:c0 + nc])
+            works[i] = (dist.all_gather_into_tensor(gb, pk, group=self.group, async_op=True), gb, c0, nc)
+
+        launch(0)
+        for i in range(len(starts)):
+            if i + 1 < len(starts):
+                launch(i + 1)
+            work, gb, c0, nc = works[i]
+            work.wait()
+            self.k.spmm(a, gb, out=dst[:, c0:c0 + nc], relu=relu)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    # ------------------------------------------------------------------- step
+    def forward(self, train):
+        k = self.k
+        keep = self.keep if train else 1.0
+        if keep < 1.0:
+            off = self.step_no * (1 << 44)
+            k.bernoulli_mask(self.n_loc * self.f, keep, self.seed * 2 + 1, off + self.row_begin * self.f,
+                             self.dev, out=self.mask1)
+            k.dropout_dense(self.x.view(-1), self.mask1, 1.0 / keep, out=self.xd.view(-1))
+            xin = self.xd
+        else:
+            xin = self.x
+        k.gemm(xin, self.w1, out=self.p1)
+        self._aggregate(self.a, self.p1, self.hb, relu=True)
+        if keep < 1.0:
+            k.bernoulli_mask(self.n_loc * self.h, keep, self.seed * 2 + 2, off + self.row_begin * self.h,
+                             self.dev, out=self.mask2)
+            k.dropout_dense(self.hb.view(-1), self.mask2, 1.0 / keep, out=self.hd.view(-1))
+            hin = self.hd
+        else:
+            hin = self.hb
+        k.gemm(hin, self.w2, out=self.p2)
+        self._aggregate(self.a, self.p2, self.z, relu=False)
+        return xin, hin
+
+    def loss(self, want_grad):
+        out, _ = self.k.masked_softmax_xent(self.z, self.y, self.ymask, want_grad=want_grad,
+                                            mask_total=self.mask_total, grad_out=self.dz)
+        return self._allreduce(out)
+
+    def train_step(self):
+        """One optimisation step.  Returns a 2-element device tensor
+        [cross-entropy part of the loss, accuracy] (before the update)."""
+        k = self.k
+        self.step_no += 1
+        xin, hin = self.forward(train=True)
+        out = self.loss(want_grad=True)
+        keep = self.keep
+        # layer 2
+        self._aggregate(self.at, self.dz, self.dp2, relu=False)            # A^T dZ
+        k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
+        k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1)                # dP2 W2^T -> dH'
+        k.relu_dropout_bwd(self.hb.view(-1), self.p1.view(-1), self.mask2 if keep < 1.0 else None,
+                           1.0 / keep, out=self.hd.view(-1))                # -> d(A P1)
+        # layer 1
+        self._aggregate(self.at, self.hd, self.hb, relu=False)             # A^T dH -> dP1
+        k.gemm(xin, self.hb, trans_a=True, out=self.g1)                     # X'^T dP1
+        self._allreduce(self.g1)
+        self._allreduce(self.g2)
+        k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)
+        k.adam_step(self.w2, self.g2, self.m2, self.v2, self.lr, self.step_no)
+        return out
+
+    def evaluate(self):
+        self.forward(train=False)
+        return self.loss(want_grad=False)
+
+    def weight_decay_loss(self):
+        return 0.5 * self.wd * float((self.w1.double() ** 2).sum().item())
+
+    # work accounting for the benchmark -------------------------------------
+    def spmm_units_per_step(self, nnz_global):
+        """nnz x width summed over the four SpMM of one training step."""
+        return nnz_global * (2 * self.h + 2 * self.c)

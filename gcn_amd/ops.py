@@ -144,7 +144,7 @@ def gemm_autograd(a, b, relu=False):
 
 
 # ------------------------------------------------------------- loss / accuracy
-def masked_softmax_xent(logits, labels, mask, want_grad=True):
+def masked_softmax_xent(logits, labels, mask, want_grad=True, mask_total=0.0, grad_out=None):
     """Returns ``(loss_acc, grad)``: ``loss_acc`` is a 2-element device tensor
     ``[loss, accuracy]`` (reference gcn/metrics.py:4-20), ``grad`` = dloss/dlogits
     or None."""
@@ -157,14 +157,14 @@ def masked_softmax_xent(logits, labels, mask, want_grad=True):
     if mask.dtype != torch.uint8 or mask.numel() != n or mask.device != logits.device:
         raise ValueError("mask must be uint8 [n] on the logits' device")
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
-    grad = torch.empty_like(logits) if want_grad else None
+    grad = (grad_out if grad_out is not None else torch.empty_like(logits)) if want_grad else None
     with torch.cuda.device(logits.device):
         need = lib.gcnx_xent_workspace_bytes(n)
         ws = WORKSPACE.get(need, logits.device)
         _lib.check(lib.gcnx_masked_softmax_xent_f32(
             n, c, _ptr(logits), logits.stride(0), _ptr(labels), labels.stride(0), _ptr(mask),
-            _ptr(out), _ptr(grad), grad.stride(0) if grad is not None else 0, _ptr(ws),
-            ws.numel(), _stream()))
+            float(mask_total), _ptr(out), _ptr(grad), grad.stride(0) if grad is not None else 0,
+            _ptr(ws), ws.numel(), _stream()))
     return out, grad
 
 
@@ -190,14 +190,19 @@ def masked_softmax_xent_autograd(logits, labels, mask):
 
 
 # ------------------------------------------------------------------ elementwise
-def bernoulli_mask(n, keep, seed, offset, device):
+def bernoulli_mask(n, keep, seed, offset, device, out=None):
     """uint8 mask, byte k = 1 with probability ``keep``, a pure function of
     (seed, offset + k) (Philox4x32-10)."""
     lib = _lib.load()
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("bernoulli_mask needs a CUDA (ROCm) device")
-    mask = torch.empty(int(n), dtype=torch.uint8, device=dev)
+    if out is not None:
+        if out.dtype != torch.uint8 or out.numel() != int(n) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor of n elements")
+        mask = out
+    else:
+        mask = torch.empty(int(n), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gcnx_bernoulli_mask_u8(int(n), float(keep), int(seed) & (2 ** 64 - 1),
                                               int(offset), _ptr(mask), _stream()))
@@ -218,12 +223,16 @@ def dropout_dense(x, mask, scale, out=None):
     return out
 
 
-def relu_dropout_bwd(y, dy, mask=None, scale=1.0):
+def relu_dropout_bwd(y, dy, mask=None, scale=1.0, out=None):
     """``dx = (y > 0 ? dy : 0)`` optionally times the dropout mask and scale."""
     lib = _lib.load()
     if y.device.type != "cuda" or not y.is_contiguous() or not dy.is_contiguous():
         raise ValueError("y and dy must be contiguous CUDA tensors")
-    dx = torch.empty_like(dy)
+    if y.numel() != dy.numel() or (mask is not None and mask.numel() != y.numel()):
+        raise ValueError("y, dy and mask differ in size")
+    dx = out if out is not None else torch.empty_like(dy)
+    if dx.numel() != dy.numel() or not dx.is_contiguous():
+        raise ValueError("out must be contiguous and as large as dy")
     with torch.cuda.device(y.device):
         _lib.check(lib.gcnx_relu_dropout_bwd_f32(y.numel(), _ptr(y), _ptr(dy), _ptr(mask),
                                                  float(scale), _ptr(dx), _stream()))
@@ -257,6 +266,18 @@ def adam_step(w, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
                                           float(lr), float(beta1), float(beta2), float(eps),
                                           float(weight_decay), int(t), _stream()))
     return w
+
+
+def profile_spmm_events(start, stop):
+    """Development / benchmark hook: the next SpMM calls of this thread record
+    ``start`` right before and ``stop`` right after their main kernel on the
+    launch stream (pass ``None, None`` to switch it off).  The arguments are
+    ``torch.cuda.Event(enable_timing=True)`` objects that have been recorded at
+    least once (so that their HIP handles exist)."""
+    lib = _lib.load()
+    a = C.c_void_p(start.cuda_event) if start is not None else C.c_void_p(0)
+    b = C.c_void_p(stop.cuda_event) if stop is not None else C.c_void_p(0)
+    lib.gcnx_profile_spmm_events(a, b)
 
 
 __all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",

@@ -116,6 +116,13 @@ int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       float mask_scale, int fuse_relu, void *ws,
                       size_t ws_bytes, void *stream);
 
+/* Measurement hook (no counterpart in the reference): while set, every
+ * gcnx_spmm_csr_f32 call made by this thread records hipEvent `start` right
+ * before and `stop` right after its main kernel, on the launch stream, so a
+ * benchmark can time that kernel alone inside a longer timed region.  Pass
+ * NULL, NULL to clear. */
+void gcnx_profile_spmm_events(void *start, void *stop);
+
 /* ---- Multi-support sum  C = act(sum_i A_i * P_i)  as ONE product -----------
  * replaces: the loop over supports plus tf.add_n, gcn/layers.py:213-221 (and
  * :195-198).  The supports are merged into one COO over interleaved columns,
@@ -152,13 +159,16 @@ int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
 /* replaces: masked_softmax_cross_entropy + masked_accuracy, gcn/metrics.py:4-20.
  * out_loss_acc[0] = mean_i(CE_i * mask_i / mean(mask)), out_loss_acc[1] = masked
  * accuracy (first maximum wins), grad (nullable) = d loss / d logits.
+ * mask_total <= 0: the masked rows are counted here.  mask_total > 0: it is the
+ * count over ALL row shards of a row-partitioned run; the outputs are then this
+ * shard's share (sum over shards = the loss / accuracy) and grad is final.
  * ws: gcnx_xent_workspace_bytes(n). */
 size_t gcnx_xent_workspace_bytes(int64_t n);
 int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const float *logits,
                                  int64_t ld, const float *labels, int64_t ldl,
-                                 const uint8_t *mask, float *out_loss_acc,
-                                 float *grad, int64_t ldg, void *ws,
-                                 size_t ws_bytes, void *stream);
+                                 const uint8_t *mask, double mask_total,
+                                 float *out_loss_acc, float *grad, int64_t ldg,
+                                 void *ws, size_t ws_bytes, void *stream);
 
 /* replaces: tf.nn.dropout on a dense activation, gcn/layers.py:210,120.
  * out = mask ? x * scale : 0; mask is one byte per element (the caller draws

@@ -1,0 +1,141 @@
+"""GPU parity of the hand-scheduled full-batch engine (the benchmark path) and
+of the synthetic-graph pipeline, against the oracle; plus size-independent
+properties at a size the oracle cannot reach."""
+import numpy as np
+import pytest
+
+from helpers import assert_close_to_f64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import oracle
+    from gcn_amd import engine, ops, rmat, sparse
+    oracle.build()
+    return dict(torch=torch, oracle=oracle, engine=engine, ops=ops, rmat=rmat, sparse=sparse,
+                dev=torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("scale,ef", [(6, 4), (10, 8), (13, 8)])
+def test_rmat_pipeline_bit_exact(env, scale, ef):
+    """Edge generation, symmetrisation, de-duplication, + I and the fp64 degree
+    normalisation on the device against numpy/scipy running the reference's
+    normalize_adj expressions on the oracle's edge list."""
+    from gcn_amd import utils
+    a = env["rmat"].rmat_ahat(scale, ef, 123, env["dev"])
+    adj_i = env["oracle"].rmat_adjacency_plus_identity(scale, ef, 0.57, 0.19, 0.19, 123)
+    ref = utils.normalize_adj(adj_i).tocsr()          # reference expressions, fp64
+    ref.sort_indices()
+    assert a.nnz == ref.nnz
+    assert np.array_equal(a.row_ptr.cpu().numpy(), ref.indptr.astype(np.int64))
+    assert np.array_equal(a.col_idx.cpu().numpy(), ref.indices.astype(np.int32))
+    got = a.val.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.data.astype(np.float32).view(np.uint32))
+
+
+def test_rmat_row_range_matches_full(env):
+    """Rows [r0, r1) built alone (as a rank of a multi-GPU run does) equal the
+    same rows of the full build."""
+    torch = env["torch"]
+    scale, ef = 11, 8
+    full = env["rmat"].rmat_ahat(scale, ef, 123, env["dev"])
+    deg = (full.row_ptr[1:] - full.row_ptr[:-1]).to(torch.int32)
+    n = 1 << scale
+    for r0, r1 in ((0, n // 4), (n // 4, n // 2), (3 * n // 4, n)):
+        part = env["rmat"].rmat_ahat(scale, ef, 123, env["dev"], r0, r1, gather_degrees=lambda local: deg)
+        s, e = int(full.row_ptr[r0]), int(full.row_ptr[r1])
+        assert part.nnz == e - s
+        assert torch.equal(part.row_ptr, full.row_ptr[r0:r1 + 1] - s)
+        assert torch.equal(part.col_idx, full.col_idx[s:e])
+        assert torch.equal(part.val, full.val[s:e])
+
+
+def _dense_tuple(x):
+    n, f = x.shape
+    r, c = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(f, dtype=np.int32), indexing="ij")
+    return (np.stack([r.ravel(), c.ravel()], 1), x.ravel().copy(), (n, f))
+
+
+@pytest.mark.parametrize("hidden,classes", [(16, 7), (128, 16)])
+def test_engine_steps_match_oracle(env, hidden, classes):
+    from oracle import model as omodel
+    torch, dev = env["torch"], env["dev"]
+    scale, f = 9, 48
+    n = 1 << scale
+    a = env["rmat"].rmat_ahat(scale, 8, 123, dev)
+    rng = np.random.RandomState(3)
+    x = rng.uniform(-1, 1, (n, f)).astype(np.float32)
+    w1 = (rng.uniform(-1, 1, (f, hidden)) * 0.2).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (hidden, classes)) * 0.2).astype(np.float32)
+    labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
+    lmask = (rng.random_sample(n) < 0.2).astype(np.uint8)
+    T = lambda v: torch.from_numpy(v).to(dev)
+    eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
+                                     T(w1), T(w2), seed=123)
+    rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    sup = (np.stack([rows, ci], 1), v, (n, n))
+    orc = omodel.TwoLayerOracle("gcn", _dense_tuple(x), [sup], [[w1], [w2]], lr=0.01, weight_decay=5e-4)
+    for step in (1, 2, 3):
+        off = step * (1 << 44)
+        m1 = env["oracle"].bernoulli_mask(n * f, 0.5, 123 * 2 + 1, off)
+        m2 = env["oracle"].bernoulli_mask(n * hidden, 0.5, 123 * 2 + 2, off)
+        logits, cache = orc.forward(m1, m2, 0.5)
+        xent, grad = env["oracle"].masked_softmax_xent(logits, labels, lmask)
+        acc = env["oracle"].masked_accuracy(logits, labels, lmask)
+        orc.adam(orc.backward(cache, grad))
+        got = eng.train_step().cpu().numpy()
+        assert abs(got[0] - xent) <= 1e-5 * abs(xent) + 1e-6, (step, got[0], xent)
+        assert abs(got[1] - acc) <= 1e-6
+        assert np.abs(eng.z.cpu().numpy() - logits).max() <= 2e-5 * np.abs(logits).max()
+        for w_gpu, w_ref in ((eng.w1, orc.w[0][0]), (eng.w2, orc.w[1][0])):
+            assert np.abs(w_gpu.cpu().numpy() - w_ref).max() <= 1e-5 * np.abs(w_ref).max() + 2e-6
+    ev = eng.evaluate().cpu().numpy()
+    logits, _ = orc.forward()
+    xent, _ = env["oracle"].masked_softmax_xent(logits, labels, lmask, want_grad=False)
+    assert abs(ev[0] - xent) <= 1e-5 * abs(xent) + 1e-6
+
+
+def test_spmm_properties_at_scale(env):
+    """RMAT scale 20 (17 M nonzeros, hub rows of ~40 k) at F=256: sampled rows
+    against an fp64 gather on the device, row sums (A_hat . 1), linearity and
+    run-to-run bitwise reproducibility."""
+    torch, dev = env["torch"], env["dev"]
+    a = env["rmat"].rmat_ahat(20, 8, 123, dev)
+    n = a.n_rows
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    b = torch.rand((n, 256), device=dev, generator=g) * 2 - 1
+    out = env["ops"].spmm(a, b)
+    out2 = env["ops"].spmm(a, b)
+    assert torch.equal(out, out2)
+    deg = (a.row_ptr[1:] - a.row_ptr[:-1])
+    hubs = torch.topk(deg, 8).indices.tolist()
+    rows = hubs + torch.randint(0, n, (200,), generator=torch.Generator().manual_seed(2)).tolist() + [0, n - 1]
+    for r in rows:
+        s, e = int(a.row_ptr[r]), int(a.row_ptr[r + 1])
+        cols = a.col_idx[s:e].long()
+        vals = a.val[s:e].double()
+        terms = vals[:, None] * b[cols].double()
+        ref, mag = terms.sum(0), terms.abs().sum(0)
+        err = (out[r].double() - ref).abs()
+        assert bool((err <= 1e-5 * mag + 1e-30).all()), (r, e - s, float(err.max()))
+    ones = torch.ones((n, 4), device=dev)
+    rs = env["ops"].spmm(a, ones)
+    assert float((rs[:, 0] - rs[:, 3]).abs().max()) == 0.0
+    # row sums via an independent route: segment sums of val in fp64
+    cs = torch.cumsum(a.val.double(), 0)
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), cs])
+    ref_rs = cs[a.row_ptr[1:]] - cs[a.row_ptr[:-1]]
+    assert float((rs[:, 0].double() - ref_rs).abs().max()) <= 1e-5 * float(ref_rs.abs().max())
+    # linearity: A(2b + c) = 2 A b + A c within rounding
+    c = torch.rand((n, 256), device=dev, generator=g)
+    lhs = env["ops"].spmm(a, 2 * b + c)
+    rhs = 2 * out + env["ops"].spmm(a, c)
+    assert float((lhs - rhs).abs().max()) <= 1e-4
+    # transpose of a symmetric matrix reproduces it bit for bit
+    t = a.transpose()
+    assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)
