@@ -194,6 +194,147 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(const SpmmArgs a) {
   }
 }
 
+// Narrow dense operands (at most 32 lanes wide): the wavefront is cut into
+// S = 64 / LW slots of LW lanes; slot s takes nonzero k0 + s of each group of S
+// consecutive nonzeros, so one load instruction gathers S different rows of B
+// (each LW*VEC*4 bytes) instead of leaving most lanes idle.  A slot accumulates
+// the terms of the current row that fall to it; when a row ends, the S slot sums
+// are added with wavefront shuffles (xor over the slot bits) and slot 0 stores.
+// Row ends inside a group are handled by range-masking the group's terms, all
+// driven by scalar comparisons.
+template <int VEC, int LW, int U>
+__global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
+  typedef typename vec_of<VEC>::type V;
+  constexpr int S = kWave / LW;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  if (c >= a.n_chunks) return;
+  const int slot = lane / LW;
+  const int col0 = (lane % LW) * VEC;
+  const bool active = col0 < a.width;
+
+  const int64_t n0 = c * (int64_t)kChunk;
+  const int64_t left = a.nnz - n0;
+  const int nk = left < (int64_t)kChunk ? (int)left : kChunk;
+
+  int64_t r = a.chunk_row[c];
+  int64_t rbase = r;
+  auto load_row_ends = [&](int64_t rb) -> int {
+    const int64_t rr = rb + 1 + lane;
+    if (rr > a.n_rows) return kRowEndBeyond;
+    const int64_t e = a.row_ptr[rr] - n0;
+    return e > (int64_t)kChunk ? kChunk + 1 : (int)e;
+  };
+  int re_v = load_row_ends(rbase);
+  int re = rl_i(re_v, 0);
+  int rs;
+  {
+    const int64_t s0 = a.row_ptr[r] - n0;
+    rs = s0 < 0 ? -1 : (int)s0;
+  }
+
+  V acc = V(0.0f);
+  float *const pslot = a.partial + (size_t)c * 2 * a.pwidth + col0;
+
+  auto reduce_slots = [&](V x) -> V {
+#pragma unroll
+    for (int off = LW; off < kWave; off <<= 1) {
+      if constexpr (VEC == 1) {
+        x += __shfl_xor(x, off, kWave);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) x[i] += __shfl_xor(x[i], off, kWave);
+      }
+    }
+    return x;
+  };
+
+  auto close_row = [&]() {
+    const V tot = reduce_slots(acc);
+    if (active && slot == 0) {
+      if (rs < 0) {
+        vstore<VEC>(pslot, tot);
+      } else {
+        epilogue_store<VEC>(a, r, col0, tot);
+      }
+    }
+    acc = V(0.0f);
+    rs = re;
+    ++r;
+    int idx = (int)(r - rbase);
+    if (idx == kWave) {
+      rbase = r;
+      re_v = load_row_ends(rbase);
+      idx = 0;
+    }
+    re = rl_i(re_v, idx);
+  };
+
+  auto load_batch = [&](int kb, int &cols, float &vals) {
+    const int k = kb + lane;
+    cols = 0;
+    vals = 0.0f;
+    if (k < nk) {
+      const int64_t g = n0 + k;
+      cols = a.col_idx[g];
+      float v = a.val[g];
+      if (a.vmask) {
+        const int64_t mi = a.mindex ? a.mindex[g] : g;
+        v = a.vmask[mi] ? v * a.mscale : 0.0f;
+      }
+      vals = v;
+    }
+  };
+
+  int cols_n;
+  float vals_n;
+  load_batch(0, cols_n, vals_n);
+
+  for (int kb = 0; kb < nk; kb += kWave) {
+    const int cols = cols_n;
+    const float vals = vals_n;
+    if (kb + kWave < nk) load_batch(kb + kWave, cols_n, vals_n);
+    const int jn = (nk - kb) < kWave ? (nk - kb) : kWave;
+    for (int j = 0; j < jn; j += U * S) {
+      V b[U];
+      float vv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = j + u * S + slot;
+        const int idc = idx < jn ? idx : (jn - 1);
+        const int cc = __shfl(cols, idc, kWave);
+        const float v = __shfl(vals, idc, kWave);
+        vv[u] = idx < jn ? v : 0.0f;
+        b[u] = V(0.0f);
+        if (active) b[u] = vload<VEC>(a.B + (int64_t)cc * a.ldb + col0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j + u * S < jn) {
+          const int g0 = kb + j + u * S;                       // first nonzero of the group
+          const int gend = (j + u * S + S) < jn ? (g0 + S) : (kb + jn);
+          const int my_k = g0 + slot;
+          const V term = (my_k < gend) ? b[u] * vv[u] : V(0.0f);
+          int lo = g0;
+          while (re <= gend) {                                 // rows ending inside this group
+            const int e = re;
+            if (my_k >= lo && my_k < e) acc += term;
+            close_row();
+            lo = e;
+          }
+          if (my_k >= lo) acc += term;
+        }
+      }
+    }
+  }
+  while (re <= nk) close_row();
+  if (r < a.n_rows && rs < nk) {
+    const V tot = reduce_slots(acc);
+    if (active && slot == 0) vstore<VEC>(pslot + (rs < 0 ? 0 : a.pwidth), tot);
+  }
+}
+
 // One wavefront per chunk boundary c | c+1: if the row that owns the first
 // nonzero of chunk c+1 begins inside chunk c, this wavefront completes it.
 template <int VEC>
@@ -332,26 +473,37 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
 
   const bool v4 = (width % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C);
   const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
-  if (v4) {
-    const unsigned gy = (unsigned)ceil_div(width, kWave * 4);
-    if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    hipLaunchKernelGGL((spmm_chunk_kernel<4, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
-    GCNX_CHECK_LAUNCH();
-    if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
-    if (k.n_chunks > 1) {
-      hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
-      GCNX_CHECK_LAUNCH();
-    }
+  const int vec = v4 ? 4 : 1;
+  const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs
+  unsigned gy = 1;
+  if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
+#define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, 4>), dim3(gx), dim3(kBlock), 0, st, k)
+  if (lanes > 32) {
+    gy = (unsigned)ceil_div(lanes, kWave);
+    if (v4) hipLaunchKernelGGL((spmm_chunk_kernel<4, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    else hipLaunchKernelGGL((spmm_chunk_kernel<1, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+  } else if (v4) {
+    if (lanes > 16) GCNX_SLOT(4, 32);
+    else if (lanes > 8) GCNX_SLOT(4, 16);
+    else if (lanes > 4) GCNX_SLOT(4, 8);
+    else if (lanes > 2) GCNX_SLOT(4, 4);
+    else if (lanes > 1) GCNX_SLOT(4, 2);
+    else GCNX_SLOT(4, 1);
   } else {
-    const unsigned gy = (unsigned)ceil_div(width, kWave);
-    if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
-    hipLaunchKernelGGL((spmm_chunk_kernel<1, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    if (lanes > 16) GCNX_SLOT(1, 32);
+    else if (lanes > 8) GCNX_SLOT(1, 16);
+    else if (lanes > 4) GCNX_SLOT(1, 8);
+    else if (lanes > 2) GCNX_SLOT(1, 4);
+    else if (lanes > 1) GCNX_SLOT(1, 2);
+    else GCNX_SLOT(1, 1);
+  }
+#undef GCNX_SLOT
+  GCNX_CHECK_LAUNCH();
+  if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+  if (k.n_chunks > 1) {
+    if (v4) hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    else hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     GCNX_CHECK_LAUNCH();
-    if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
-    if (k.n_chunks > 1) {
-      hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
-      GCNX_CHECK_LAUNCH();
-    }
   }
   return GCNX_OK;
 }

@@ -96,7 +96,7 @@ def _spmm_case(env, n_rows, n_cols, nnz, width, hub=(), empty=(), seed=0, **kw):
     return a, b, rp, ci, v, perm, rng
 
 
-@pytest.mark.parametrize("width", [1, 3, 7, 16, 60, 64, 100, 128, 256, 260, 512])
+@pytest.mark.parametrize("width", [1, 2, 3, 4, 7, 8, 12, 16, 20, 31, 32, 33, 60, 64, 100, 128, 132, 256, 260, 512])
 @pytest.mark.parametrize("shape", [
     (1, 1, 1), (50, 40, 0), (300, 200, 511), (300, 200, 512), (300, 200, 513),
     (2000, 1500, 30000), (20000, 20000, 90000),
@@ -111,7 +111,7 @@ def test_spmm_matches_oracle(env, shape, width):
     assert rel_maxnorm(got, ref32) <= RTOL
 
 
-@pytest.mark.parametrize("width", [7, 16, 256])
+@pytest.mark.parametrize("width", [1, 7, 16, 64, 128, 256])
 def test_spmm_hub_and_empty_rows(env, width):
     """Rows far longer than a chunk (completed from partial sums), runs of empty
     rows at the start, the end and across chunk boundaries."""
