@@ -44,3 +44,88 @@ def random_coo(rng, n_rows, n_cols, nnz, hub_rows=(), empty_rows=(), dup_frac=0.
         rows, cols = rows[keep], cols[keep]
     vals = rng.standard_normal(len(rows))
     return rows, cols, vals
+
+
+class CpuCsr(object):
+    """Host stand-in for gcn_amd.sparse.Csr used by the CPU distributed tests."""
+
+    def __init__(self, m):
+        m = m.tocsr()
+        m.sort_indices()
+        self.n_rows, self.n_cols = m.shape
+        self.nnz = m.nnz
+        self.row_ptr = m.indptr.astype(np.int64)
+        self.col_idx = m.indices.astype(np.int32)
+        self.val = m.data.astype(np.float32)
+
+
+class OracleKernels(object):
+    """The engine's kernel interface answered by the CPU oracle, so that the
+    partition / all-gather / all-reduce logic of gcn_amd.engine can be exercised
+    with the gloo backend on a machine without GPUs.  Test-only: the product
+    default is gcn_amd.ops (HIP)."""
+
+    def __init__(self):
+        import torch
+        import oracle
+        self.torch, self.o = torch, oracle
+
+    def spmm(self, a, b, out=None, relu=False, **kw):
+        r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
+        if relu:
+            r = np.maximum(r, 0)
+        t = self.torch.from_numpy(r)
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    def gemm(self, a, b, trans_a=False, trans_b=False, out=None, **kw):
+        r = self.torch.from_numpy(self.o.gemm(a.contiguous().numpy(), b.contiguous().numpy(), trans_a, trans_b))
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def bernoulli_mask(self, n, keep, seed, offset, device, out=None):
+        m = self.torch.from_numpy(self.o.bernoulli_mask(n, keep, seed, offset))
+        if out is None:
+            return m
+        out.copy_(m)
+        return out
+
+    def dropout_dense(self, x, mask, scale, out=None):
+        r = self.torch.where(mask.view(x.shape) != 0, x * scale, self.torch.zeros_like(x))
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def relu_dropout_bwd(self, y, dy, mask=None, scale=1.0, out=None):
+        g = dy if mask is None else self.torch.where(mask.view(dy.shape) != 0, dy * scale, self.torch.zeros_like(dy))
+        r = self.torch.where(y > 0, g, self.torch.zeros_like(g))
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def masked_softmax_xent(self, logits, labels, mask, want_grad=True, mask_total=0.0, grad_out=None):
+        z, y, m = logits.numpy(), labels.numpy(), mask.numpy()
+        local = float(m.sum())
+        total = mask_total if mask_total > 0 else local
+        loss, grad = self.o.masked_softmax_xent(z, y, m, want_grad)
+        acc = self.o.masked_accuracy(z, y, m)
+        share = local / total if total > 0 else 0.0
+        out = self.torch.tensor([loss * share, acc * share], dtype=self.torch.float32)
+        if want_grad:
+            g = self.torch.from_numpy(grad * np.float32(share))
+            if grad_out is not None:
+                grad_out.copy_(g)
+                g = grad_out
+            return out, g
+        return out, None
+
+    def adam_step(self, w, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+        g = (grad + weight_decay * w).contiguous().numpy().astype(np.float32)
+        self.o.adam_step(w.numpy(), g, m.numpy(), v.numpy(), lr, t, beta1, beta2, eps)
+        return w

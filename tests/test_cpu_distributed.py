@@ -1,0 +1,112 @@
+"""world_size-2 tests of the row-partitioned engine on the gloo backend (CPU).
+The kernels are answered by the oracle (tests/helpers.OracleKernels); what is
+under test is the partition, the slabbed all-gather of the dense operand, the
+all-reduce of weight gradients / loss, and the rule that dropout masks depend on
+the global element index only, so that 1-rank and 2-rank runs agree."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import CpuCsr, OracleKernels  # noqa: E402
+
+
+def _problem(scale=7, f=12, hidden=16, classes=5):
+    import oracle
+    from gcn_amd import utils
+    n = 1 << scale
+    adj_i = oracle.rmat_adjacency_plus_identity(scale, 4, 0.57, 0.19, 0.19, 123)
+    a_hat = utils.normalize_adj(adj_i).tocsr().astype(np.float32)
+    rng = np.random.RandomState(0)
+    x = rng.uniform(-1, 1, (n, f)).astype(np.float32)
+    w1 = (rng.uniform(-1, 1, (f, hidden)) * 0.3).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (hidden, classes)) * 0.3).astype(np.float32)
+    labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
+    lmask = (rng.random_sample(n) < 0.3).astype(np.uint8)
+    return n, a_hat, x, w1, w2, labels, lmask, hidden, classes
+
+
+def _run(rank, world, port, slab, out_dir):
+    from gcn_amd import engine
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem()
+    n_loc = n // world
+    rb, re_ = rank * n_loc, (rank + 1) * n_loc
+    T = torch.from_numpy
+    eng = engine.FullBatchGCN(
+        CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
+        int(lmask.sum()), hidden, classes, T(w1), T(w2), row_begin=rb, n_global=n, seed=5,
+        group=dist.group.WORLD if world > 1 else None, world_size=world, slab_cols=slab,
+        kernels=OracleKernels())
+    outs = [eng.train_step().numpy().copy() for _ in range(3)]
+    ev = eng.evaluate().numpy().copy()
+    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), outs=np.stack(outs), ev=ev,
+             w1=eng.w1.numpy(), w2=eng.w2.numpy(), z=eng.z.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("slab", [16, 8])
+def test_two_ranks_match_one_rank(tmp_path, slab):
+    out = str(tmp_path)
+    _run(0, 1, 0, None, out)
+    mp.spawn(_run, args=(2, _free_port(), slab, out), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "w2_r0.npz"))
+    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    # replicated state is identical on both ranks
+    assert np.array_equal(r0["w1"], r1["w1"]) and np.array_equal(r0["w2"], r1["w2"])
+    assert np.array_equal(r0["outs"], r1["outs"])
+    # and equals the single-rank run up to the association of the two partial sums
+    np.testing.assert_allclose(r0["outs"], one["outs"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r0["ev"], one["ev"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r0["w1"], one["w1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
+    z = np.concatenate([r0["z"], r1["z"]])
+    np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
+
+
+def test_single_rank_matches_model_oracle():
+    """The engine's schedule (buffer reuse, fused backward steps) against the
+    independent model restatement in oracle/model.py."""
+    import oracle
+    from oracle import model as omodel
+    from gcn_amd import engine
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem()
+    T = torch.from_numpy
+    eng = engine.FullBatchGCN(CpuCsr(a_hat), T(x.copy()), T(labels.copy()), T(lmask.copy()), int(lmask.sum()),
+                              hidden, classes, T(w1), T(w2), seed=5, kernels=OracleKernels())
+    coo = a_hat.tocoo()
+    sup = (np.stack([coo.row, coo.col], 1).astype(np.int32), coo.data, (n, n))
+    f = x.shape[1]
+    r, c = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(f, dtype=np.int32), indexing="ij")
+    feats = (np.stack([r.ravel(), c.ravel()], 1), x.ravel().copy(), (n, f))
+    orc = omodel.TwoLayerOracle("gcn", feats, [sup], [[w1], [w2]], lr=0.01, weight_decay=5e-4)
+    for step in (1, 2):
+        off = step * (1 << 44)
+        m1 = oracle.bernoulli_mask(n * f, 0.5, 5 * 2 + 1, off)
+        m2 = oracle.bernoulli_mask(n * hidden, 0.5, 5 * 2 + 2, off)
+        logits, cache = orc.forward(m1, m2, 0.5)
+        xent, grad = oracle.masked_softmax_xent(logits, labels, lmask)
+        orc.adam(orc.backward(cache, grad))
+        got = eng.train_step().numpy()
+        assert abs(got[0] - xent) <= 1e-5 * abs(xent)
+        np.testing.assert_allclose(eng.w1.numpy(), orc.w[0][0], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(eng.w2.numpy(), orc.w[1][0], rtol=0, atol=2e-6)
