@@ -58,6 +58,8 @@ SIGNATURES = {
                                             _p, _sz, _p]),
     "gcnx_dropout_dense_f32": (_int, [_i64, _p, _p, _f32, _p, _p]),
     "gcnx_bernoulli_mask_u8": (_int, [_i64, _f32, _u64, _u64, _p, _p]),
+    "gcnx_dropout_philox_f32": (_int, [_i64, _p, _f32, _u64, _u64, _p, _p, _p]),
+    "gcnx_relu_dropout_bwd_philox_f32": (_int, [_i64, _p, _p, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),
     "gcnx_adam_step_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
     "gcnx_normalize_csr_f64": (_int, [_csr_p, _i64, _p, _p, _i64, _p, _p, _p]),

@@ -196,6 +196,127 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// MFMA kernel for the weight gradients  C[M,N] = A^T * B  with A stored [K, M],
+// B stored [K, N] and K = the node dimension (huge), split along K over
+// grid.z.  The A operand of v_mfma_f32_32x32x2_f32 wants A_op[i][k] = A[k][i]:
+// for a fixed k the 32 values are contiguous in memory, so both operands are
+// staged in LDS exactly as they lie in HBM ([k][m] and [k][n]) and fragment
+// reads are conflict free.  Block tile 128 x BN: BN = 128 -> wavefronts 2 x 2,
+// each 64 x 64 (four accumulator tiles); BN = 32 -> wavefronts 4 x 1, each
+// 32 x 32 (the class-dimension case, N <= 32, columns beyond N read as zero).
+// Every split writes its tile to the workspace; gemm_reduce_kernel adds the
+// splits in order.
+// ---------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(kBlock) void gemm_mfma_tn_kernel(const GemmArgs g) {
+  constexpr int BM = 128, BK = 16;
+  constexpr int WN = BN == 128 ? 2 : 1;          // wavefronts along N
+  constexpr int WM = 4 / WN;                     // wavefronts along M
+  constexpr int TMW = BM / (32 * WM);            // accumulator tiles per wavefront along M
+  constexpr int TNW = BN / (32 * WN);
+  __shared__ float As[BK * BM];
+  __shared__ float Bs[BK * BN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int wm = w / WN, wn = w % WN;
+  const int li = lane & 31, lk = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  f16v acc[TMW][TNW];
+#pragma unroll
+  for (int a = 0; a < TMW; ++a)
+#pragma unroll
+    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  for (int64_t kk = kbeg; kk < kend; kk += BK) {
+    // A: 16 rows x 128 floats = 512 float4, two per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (kk + k < kend) v = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      *reinterpret_cast<f4v *>(As + k * BM + q * 4) = v;
+    }
+    if constexpr (BN == 128) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e >> 5, q = e & 31;
+        f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (kk + k < kend) v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e >> 5, n = e & 31;
+        float v = 0.0f;
+        if (kk + k < kend && n0 + n < g.N) v = g.B[(kk + k) * g.ldb + n0 + n];
+        Bs[k * BN + n] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < BK; k2 += 2) {
+      float af[TMW], bf[TNW];
+#pragma unroll
+      for (int a = 0; a < TMW; ++a) af[a] = As[(k2 + lk) * BM + (wm * TMW + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TNW; ++b) bf[b] = Bs[(k2 + lk) * BN + (wn * TNW + b) * 32 + li];
+#pragma unroll
+      for (int a = 0; a < TMW; ++a)
+#pragma unroll
+        for (int b = 0; b < TNW; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < TMW; ++a)
+#pragma unroll
+    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+      for (int rgi = 0; rgi < 16; ++rgi) {
+        const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
+        const int64_t gm = m0 + (wm * TMW + a) * 32 + row;
+        const int64_t gn = n0 + (wn * TNW + b) * 32 + li;
+        if (gm >= g.M || gn >= g.N) continue;
+        if (g.splits > 1) {
+          g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[a][b][rgi];
+        } else {
+          float *dst = g.C + gm * g.ldc + gn;
+          float out = g.alpha * acc[a][b][rgi];
+          if (g.beta != 0.0f) out += g.beta * *dst;
+          if (g.relu) out = fmaxf(out, 0.0f);
+          *dst = out;
+        }
+      }
+}
+
+// Shapes served by gemm_mfma_tn_kernel (transposed A, plain B).
+static bool tn_mfma_shape(int64_t M, int64_t N, int64_t K) {
+  return M >= 64 && M % 128 == 0 && K >= 4096 && (N % 128 == 0 || N <= 32);
+}
+
+static int tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t bn = N % 128 == 0 ? 128 : 32;
+  const int64_t tiles = (M / 128) * ceil_div(N, bn);
+  int64_t s = 2048 / tiles;
+  const int64_t max_s = ceil_div(K, 1024);
+  if (s > max_s) s = max_s;
+  if (s > 65535) s = 65535;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 static int choose_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, TM) * ceil_div(N, TN);
   if (tiles >= 1024 || K <= 4096) return 1;
@@ -216,7 +337,8 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
                                             int64_t K) {
   (void)trans_a; (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int s = choose_splits(M, N, K);
+  const int s = (trans_a && !trans_b && tn_mfma_shape(M, N, K)) ? tn_mfma_splits(M, N, K)
+                                                                : choose_splits(M, N, K);
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -246,6 +368,33 @@ extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     GCNX_REQUIRE(mt <= 0x7fffffffll && N / NB <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
     hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)mt, (unsigned)(N / NB)), dim3(kBlock), 0, st, g);
     GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+
+  const bool tn_ok = trans_a && !trans_b && tn_mfma_shape(M, N, K) && (lda % 4 == 0) &&
+                     aligned16(A) && (N > 32 ? (ldb % 4 == 0 && aligned16(B)) : true);
+  if (tn_ok) {
+    const int sp = tn_mfma_splits(M, N, K);
+    if (sp > 1) {
+      const size_t need = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+      GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
+                   "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
+      g.partial = static_cast<float *>(ws);
+      g.splits = sp;
+      g.k_per_split = ceil_div(ceil_div(K, sp), 16) * 16;
+    }
+    if (N % 128 == 0) {
+      hipLaunchKernelGGL((gemm_mfma_tn_kernel<128>), dim3((unsigned)(M / 128), (unsigned)(N / 128), (unsigned)g.splits),
+                         dim3(kBlock), 0, st, g);
+    } else {
+      hipLaunchKernelGGL((gemm_mfma_tn_kernel<32>), dim3((unsigned)(M / 128), 1u, (unsigned)g.splits),
+                         dim3(kBlock), 0, st, g);
+    }
+    GCNX_CHECK_LAUNCH();
+    if (g.splits > 1) {
+      hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
+      GCNX_CHECK_LAUNCH();
+    }
     return GCNX_OK;
   }
 

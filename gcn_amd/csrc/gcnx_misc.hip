@@ -97,6 +97,58 @@ __global__ __launch_bounds__(kBlock) void xent_rows_kernel(
   if (threadIdx.x == 0) hit_part[blockIdx.x] = hit;
 }
 
+// Same computation with a row spread over G = pow2 >= n_class lanes (G <= 64):
+// lane j of a group holds class j, so logits / labels / grad are read and written
+// fully coalesced and the row maxima, sums and first-maximum indices are formed
+// with wavefront shuffles inside the group.
+template <int G>
+__global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
+    int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
+    const float *__restrict__ labels, int64_t ldl, const uint8_t *__restrict__ mask,
+    const double *__restrict__ msum_p, float *__restrict__ grad, int64_t ldg,
+    double *__restrict__ loss_part, double *__restrict__ hit_part) {
+  __shared__ double sh[kWavesPerBlock];
+  constexpr int RPB = kBlock / G;  // rows per block and pass
+  const double msum = *msum_p;
+  const float wgt = msum > 0.0 ? (float)(1.0 / msum) : 0.0f;
+  const int sub = threadIdx.x % G;
+  const bool in = sub < nc;
+  double loss = 0.0, hit = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n; base += (int64_t)gridDim.x * RPB) {
+    const int64_t row = base + threadIdx.x / G;
+    const bool valid = row < n;
+    const float ninf = -__builtin_inff();
+    const float z = (valid && in) ? logits[row * ld + sub] : ninf;
+    const float y = (valid && in) ? labels[row * ldl + sub] : ninf;
+    float zmax = z, ymax = y;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+      zmax = fmaxf(zmax, __shfl_xor(zmax, off, kWave));
+      ymax = fmaxf(ymax, __shfl_xor(ymax, off, kWave));
+    }
+    int az = (in && z == zmax) ? sub : G, ay = (in && y == ymax) ? sub : G;  // first maximum wins
+    const float e = (valid && in) ? __expf(z - zmax) : 0.0f;
+    float se = e, ysum = (valid && in) ? y : 0.0f;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+      az = min(az, __shfl_xor(az, off, kWave));
+      ay = min(ay, __shfl_xor(ay, off, kWave));
+      se += __shfl_xor(se, off, kWave);
+      ysum += __shfl_xor(ysum, off, kWave);
+    }
+    if (valid) {
+      const bool on = mask[row] != 0;
+      if (on && in) loss += (double)(-y * ((z - zmax) - __logf(se)));
+      if (on && sub == 0 && az == ay) hit += 1.0;
+      if (grad && in) grad[row * ldg + sub] = (e / se * ysum - y) * (on ? wgt : 0.0f);
+    }
+  }
+  loss = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) hit_part[blockIdx.x] = hit;
+}
+
 __global__ __launch_bounds__(kBlock) void xent_final_kernel(int nb, const double *__restrict__ ws_msum,
                                                            const double *__restrict__ loss_part,
                                                            const double *__restrict__ hit_part,
@@ -209,6 +261,59 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kernel(int64_t n, float keep
   }
 }
 
+// Dropout with the mask regenerated from Philox instead of read from memory:
+// element i is kept iff uniform(seed, offset + i) < keep (the same rule and bits
+// as bernoulli_kernel).  MODE 0: out = keep_i ? x * scale : 0.  MODE 1 (backward
+// through relu then dropout): out = (y > 0 && keep_i) ? dy * scale : 0, with
+// x = dy and y the relu output.  Four consecutive global positions share one
+// Philox block; with offset % 4 == 0 and aligned pointers a thread handles one
+// block with 16-byte accesses.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void dropout_philox_kernel(
+    int64_t n, const float *__restrict__ x, const float *__restrict__ y, float keep, float scale,
+    uint64_t seed, uint64_t offset, float *__restrict__ out, uint8_t *__restrict__ mask_out,
+    int vec_ok) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec_ok) {
+    const int64_t n4 = n / 4;
+    const uint64_t blk0 = offset >> 2;
+    for (int64_t i = tid; i < n4; i += stride) {
+      const philox4 r = philox4x32_10(blk0 + (uint64_t)i, 0ull, seed);
+      const f4 v = reinterpret_cast<const f4 *>(x)[i];
+      f4 yy = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (MODE == 1) yy = reinterpret_cast<const f4 *>(y)[i];
+      f4 o;
+      u8x4 m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool kp = (float)(r.v[j] >> 8) * (1.0f / 16777216.0f) < keep;
+        m[j] = kp ? 1 : 0;
+        o[j] = (kp && yy[j] > 0.0f) ? v[j] * scale : 0.0f;
+      }
+      reinterpret_cast<f4 *>(out)[i] = o;
+      if (mask_out) reinterpret_cast<u8x4 *>(mask_out)[i] = m;
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += stride) {
+      const uint64_t e = offset + (uint64_t)i;
+      const philox4 r = philox4x32_10(e >> 2, 0ull, seed);
+      const bool kp = (float)(r.v[e & 3] >> 8) * (1.0f / 16777216.0f) < keep;
+      const float yv = MODE == 1 ? y[i] : 1.0f;
+      out[i] = (kp && yv > 0.0f) ? x[i] * scale : 0.0f;
+      if (mask_out) mask_out[i] = kp ? 1 : 0;
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += stride) {
+      const uint64_t e = offset + (uint64_t)i;
+      const philox4 r = philox4x32_10(e >> 2, 0ull, seed);
+      const bool kp = (float)(r.v[e & 3] >> 8) * (1.0f / 16777216.0f) < keep;
+      const float yv = MODE == 1 ? y[i] : 1.0f;
+      out[i] = (kp && yv > 0.0f) ? x[i] * scale : 0.0f;
+      if (mask_out) mask_out[i] = kp ? 1 : 0;
+    }
+  }
+}
+
 __device__ __forceinline__ int64_t row_of_slot2(const int64_t *row_ptr, int64_t n_rows, int64_t s) {
   int64_t lo = 0, hi = n_rows;
   while (hi - lo > 1) {
@@ -294,8 +399,20 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
     hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(kBlock), 0, st, n, mask, cnt);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, nb, cnt, msum);
   }
-  hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
-                     ldl, mask, msum, grad, ldg, lp, hp);
+#define GCNX_XENT(G)                                                                          \
+  hipLaunchKernelGGL((xent_rows_group_kernel<G>), dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, \
+                     ld, labels, ldl, mask, msum, grad, ldg, lp, hp)
+  if (n_class > 64) {
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
+                       ldl, mask, msum, grad, ldg, lp, hp);
+  } else if (n_class > 32) GCNX_XENT(64);
+  else if (n_class > 16) GCNX_XENT(32);
+  else if (n_class > 8) GCNX_XENT(16);
+  else if (n_class > 4) GCNX_XENT(8);
+  else if (n_class > 2) GCNX_XENT(4);
+  else if (n_class > 1) GCNX_XENT(2);
+  else GCNX_XENT(1);
+#undef GCNX_XENT
   hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, lp, hp, out_loss_acc);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
@@ -343,6 +460,35 @@ extern "C" int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed, uint
   if (n == 0) return GCNX_OK;
   hipLaunchKernelGGL(bernoulli_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
                      as_stream(stream), n, keep, seed, offset, mask);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_dropout_philox_f32(int64_t n, const float *x, float keep, uint64_t seed,
+                                       uint64_t offset, float *out, uint8_t *mask_out,
+                                       void *stream) {
+  GCNX_REQUIRE(n >= 0 && keep > 0.0f && (n == 0 || (x && out)), GCNX_ERR_INVALID_ARG,
+               "dropout_philox: bad argument");
+  if (n == 0) return GCNX_OK;
+  const int vec_ok = aligned16(x) && aligned16(out) && (!mask_out || aligned4(mask_out)) &&
+                     (offset % 4 == 0);
+  hipLaunchKernelGGL((dropout_philox_kernel<0>), dim3(stream_grid(n / 4 + 1)), dim3(kBlock), 0,
+                     as_stream(stream), n, x, (const float *)nullptr, keep, 1.0f / keep, seed, offset,
+                     out, mask_out, vec_ok);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_relu_dropout_bwd_philox_f32(int64_t n, const float *y, const float *dy,
+                                                float keep, uint64_t seed, uint64_t offset,
+                                                float *dx, void *stream) {
+  GCNX_REQUIRE(n >= 0 && keep > 0.0f && (n == 0 || (y && dy && dx)), GCNX_ERR_INVALID_ARG,
+               "relu_dropout_bwd_philox: bad argument");
+  if (n == 0) return GCNX_OK;
+  const int vec_ok = aligned16(y) && aligned16(dy) && aligned16(dx) && (offset % 4 == 0);
+  hipLaunchKernelGGL((dropout_philox_kernel<1>), dim3(stream_grid(n / 4 + 1)), dim3(kBlock), 0,
+                     as_stream(stream), n, dy, y, keep, 1.0f / keep, seed, offset, dx,
+                     (uint8_t *)nullptr, vec_ok);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

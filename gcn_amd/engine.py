@@ -70,8 +70,10 @@ class FullBatchGCN(object):
         self.dz = e(nl, self.c)
         self.dp2 = e(nl, self.c)
         self.g1, self.g2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
-        self.mask1 = e(nl * self.f, dtype=torch.uint8) if self.keep < 1.0 else None
-        self.mask2 = e(nl * self.h, dtype=torch.uint8) if self.keep < 1.0 else None
+        # dropout masks are regenerated from Philox where they are needed; they
+        # are only stored when a caller asks for them (keep_masks, for tests)
+        self.mask1 = e(nl * self.f, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
+        self.mask2 = e(nl * self.h, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
         # gather buffers (only with more than one rank)
         if self.world > 1:
             if slab_cols is None:
@@ -125,18 +127,16 @@ class FullBatchGCN(object):
         keep = self.keep if train else 1.0
         if keep < 1.0:
             off = self.step_no * (1 << 44)
-            k.bernoulli_mask(self.n_loc * self.f, keep, self.seed * 2 + 1, off + self.row_begin * self.f,
-                             self.dev, out=self.mask1)
-            k.dropout_dense(self.x.view(-1), self.mask1, 1.0 / keep, out=self.xd.view(-1))
+            k.dropout_philox(self.x.view(-1), keep, self.seed * 2 + 1, off + self.row_begin * self.f,
+                             out=self.xd.view(-1), mask_out=self.mask1)
             xin = self.xd
         else:
             xin = self.x
         k.gemm(xin, self.w1, out=self.p1)
         self._aggregate(self.a, self.p1, self.hb, relu=True)
         if keep < 1.0:
-            k.bernoulli_mask(self.n_loc * self.h, keep, self.seed * 2 + 2, off + self.row_begin * self.h,
-                             self.dev, out=self.mask2)
-            k.dropout_dense(self.hb.view(-1), self.mask2, 1.0 / keep, out=self.hd.view(-1))
+            k.dropout_philox(self.hb.view(-1), keep, self.seed * 2 + 2, off + self.row_begin * self.h,
+                             out=self.hd.view(-1), mask_out=self.mask2)
             hin = self.hd
         else:
             hin = self.hb
@@ -161,8 +161,13 @@ class FullBatchGCN(object):
         self._aggregate(self.at, self.dz, self.dp2, relu=False)            # A^T dZ
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1)                # dP2 W2^T -> dH'
-        k.relu_dropout_bwd(self.hb.view(-1), self.p1.view(-1), self.mask2 if keep < 1.0 else None,
-                           1.0 / keep, out=self.hd.view(-1))                # -> d(A P1)
+        if keep < 1.0:
+            off = self.step_no * (1 << 44)
+            k.relu_dropout_bwd_philox(self.hb.view(-1), self.p1.view(-1), keep, self.seed * 2 + 2,
+                                      off + self.row_begin * self.h, out=self.hd.view(-1))
+        else:
+            k.relu_dropout_bwd(self.hb.view(-1), self.p1.view(-1), None, 1.0, out=self.hd.view(-1))
+        # hd now holds d(A P1)
         # layer 1
         self._aggregate(self.at, self.hd, self.hb, relu=False)             # A^T dH -> dP1
         k.gemm(xin, self.hb, trans_a=True, out=self.g1)                     # X'^T dP1

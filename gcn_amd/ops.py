@@ -239,6 +239,37 @@ def relu_dropout_bwd(y, dy, mask=None, scale=1.0, out=None):
     return dx
 
 
+def dropout_philox(x, keep, seed, offset, out=None, mask_out=None):
+    """``out = kept ? x / keep : 0`` with the Bernoulli(keep) mask regenerated
+    from Philox (seed, offset + i): same bits as :func:`bernoulli_mask`."""
+    lib = _lib.load()
+    if x.device.type != "cuda" or x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous float32 CUDA tensor")
+    if out is None:
+        out = torch.empty_like(x)
+    if out.numel() != x.numel() or not out.is_contiguous():
+        raise ValueError("out must be contiguous and as large as x")
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gcnx_dropout_philox_f32(x.numel(), _ptr(x), float(keep),
+                                               int(seed) & (2 ** 64 - 1), int(offset), _ptr(out),
+                                               _ptr(mask_out), _stream()))
+    return out
+
+
+def relu_dropout_bwd_philox(y, dy, keep, seed, offset, out=None):
+    """``dx = (y > 0 and kept) ? dy / keep : 0`` with the mask of
+    :func:`dropout_philox` regenerated."""
+    lib = _lib.load()
+    if y.device.type != "cuda" or not y.is_contiguous() or not dy.is_contiguous() or y.numel() != dy.numel():
+        raise ValueError("y and dy must be contiguous CUDA tensors of one size")
+    dx = out if out is not None else torch.empty_like(dy)
+    with torch.cuda.device(y.device):
+        _lib.check(lib.gcnx_relu_dropout_bwd_philox_f32(y.numel(), _ptr(y), _ptr(dy), float(keep),
+                                                        int(seed) & (2 ** 64 - 1), int(offset),
+                                                        _ptr(dx), _stream()))
+    return dx
+
+
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, scale):
@@ -282,4 +313,4 @@ def profile_spmm_events(start, stop):
 
 __all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",
            "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
-           "dropout_dense_autograd", "relu_dropout_bwd", "adam_step"]
+           "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "adam_step"]

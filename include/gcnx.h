@@ -182,6 +182,20 @@ int gcnx_dropout_dense_f32(int64_t n, const float *x, const uint8_t *mask,
 int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed,
                            uint64_t offset, uint8_t *mask, void *stream);
 
+/* The same two steps fused, the mask never touching memory: element i is kept
+ * iff the Philox uniform of (seed, offset + i) is < keep (bit-identical to
+ * gcnx_bernoulli_mask_u8), survivors scaled by 1/keep.  mask_out (nullable)
+ * also stores the mask.  replaces: gcn/layers.py:210,120 + :24. */
+int gcnx_dropout_philox_f32(int64_t n, const float *x, float keep, uint64_t seed,
+                            uint64_t offset, float *out, uint8_t *mask_out,
+                            void *stream);
+
+/* Backward of relu followed by that dropout, mask regenerated from
+ * (seed, offset): dx = (y > 0 && kept_i) ? dy / keep : 0; y = relu output. */
+int gcnx_relu_dropout_bwd_philox_f32(int64_t n, const float *y, const float *dy,
+                                     float keep, uint64_t seed, uint64_t offset,
+                                     float *dx, void *stream);
+
 /* dx = (y > 0 ? dy : 0) [* mask * scale]: backward of act=relu
  * (gcn/layers.py:226) fused with the backward of the next layer's dropout
  * (gcn/layers.py:210).  y is the relu OUTPUT.  mask nullable. */

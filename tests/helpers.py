@@ -101,6 +101,16 @@ class OracleKernels(object):
         out.copy_(r)
         return out
 
+    def dropout_philox(self, x, keep, seed, offset, out=None, mask_out=None):
+        m = self.torch.from_numpy(self.o.bernoulli_mask(x.numel(), keep, seed, offset))
+        if mask_out is not None:
+            mask_out.copy_(m)
+        return self.dropout_dense(x, m, 1.0 / keep, out=out)
+
+    def relu_dropout_bwd_philox(self, y, dy, keep, seed, offset, out=None):
+        m = self.torch.from_numpy(self.o.bernoulli_mask(y.numel(), keep, seed, offset))
+        return self.relu_dropout_bwd(y, dy, m, 1.0 / keep, out=out)
+
     def relu_dropout_bwd(self, y, dy, mask=None, scale=1.0, out=None):
         g = dy if mask is None else self.torch.where(mask.view(dy.shape) != 0, dy * scale, self.torch.zeros_like(dy))
         r = self.torch.where(y > 0, g, self.torch.zeros_like(g))

@@ -193,6 +193,7 @@ def test_spmm_reproducible_and_strided(env):
     (0, 0, 1, 1, 1), (0, 0, 2708, 7, 16), (0, 0, 1000, 16, 1433), (0, 0, 4096, 256, 256),
     (0, 0, 700, 128, 64), (0, 0, 513, 100, 37), (0, 1, 2708, 16, 7), (0, 1, 3000, 256, 16),
     (1, 0, 16, 7, 2708), (1, 0, 256, 16, 100000), (1, 0, 256, 256, 20000), (1, 1, 33, 21, 65),
+    (1, 0, 128, 7, 5000), (1, 0, 384, 128, 9999), (1, 0, 256, 32, 4100),
 ])
 def test_gemm_matches_oracle(env, ta, tb, M, N, K):
     torch = env["torch"]
@@ -278,3 +279,21 @@ def test_dropout_relu_bwd_adam(env):
         env["oracle"].adam_step(w, (g + np.float32(5e-4) * w).astype(np.float32), m, v, 0.01, t)
     assert np.abs(wt.cpu().numpy() - w).max() <= 1e-6
     assert np.abs(mt_.cpu().numpy() - m).max() <= 1e-7
+
+
+def test_dropout_philox_matches_mask_path(env):
+    """The fused kernels regenerate exactly the mask gcnx_bernoulli_mask_u8 writes."""
+    torch = env["torch"]
+    rng = np.random.RandomState(8)
+    for n, off in ((1, 0), (1027, 4), (1027, 3), (100003, 5 * (1 << 44) + 256 * 77)):
+        x = rng.standard_normal(n).astype(np.float32)
+        dy = rng.standard_normal(n).astype(np.float32)
+        y = np.maximum(rng.standard_normal(n), 0).astype(np.float32)
+        xt, dyt, yt = (torch.from_numpy(t).to(env["dev"]) for t in (x, dy, y))
+        mask = env["oracle"].bernoulli_mask(n, 0.5, 247, off)
+        mo = torch.zeros(n, dtype=torch.uint8, device=env["dev"])
+        got = env["ops"].dropout_philox(xt, 0.5, 247, off, mask_out=mo).cpu().numpy()
+        assert np.array_equal(mo.cpu().numpy(), mask)
+        assert np.array_equal(got, np.where(mask != 0, x * np.float32(2.0), np.float32(0)))
+        got = env["ops"].relu_dropout_bwd_philox(yt, dyt, 0.5, 247, off).cpu().numpy()
+        assert np.array_equal(got, np.where((y > 0) & (mask != 0), dy * np.float32(2.0), np.float32(0)))
