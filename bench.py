@@ -87,8 +87,12 @@ def main():
     ap.add_argument("--classes", type=int, default=16)
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU-baseline slice (0 = skip)")
     ap.add_argument("--slab-cols", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
+                    "ranks sharing one GPU)")
     args = ap.parse_args()
 
+    t_start = time.time()
     import torch
     import torch.distributed as dist
     from gcn_amd import engine, ops, rmat
@@ -100,14 +104,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if world & (world - 1):
         raise SystemExit("the number of GPUs must be a power of two")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
         group = dist.group.WORLD
 
+    def note(msg):
+        if args.verbose:
+            print("[rank %d %.1fs] %s" % (rank, time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    note("process group up (backend %s)" % (args.backend if world > 1 else "none"))
     scale = args.scale or (24 + int(math.log2(world)))
     n = 1 << scale
     n_loc = n // world
@@ -118,12 +130,17 @@ def main():
     def gather_degrees(local):
         if world == 1:
             return local
+        if args.backend != "nccl":
+            host = torch.empty(n, dtype=torch.int32)
+            dist.all_gather_into_tensor(host, local.cpu().contiguous(), group=group)
+            return host.to(dev)
         out = torch.empty(n, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
 
     t_build = time.time()
     a = rmat.rmat_ahat(scale, args.edge_factor, seed, dev, rb, re_, gather_degrees if world > 1 else None)
+    note("graph shard built: %d rows, %d nonzeros" % (a.n_rows, a.nnz))
     nnz_t = torch.tensor([a.nnz], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(nnz_t, group=group)
@@ -148,7 +165,19 @@ def main():
     mask_total = world * max(1, n_loc // 100)
     del cls
 
-    model = engine.FullBatchGCN(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
+    engine_cls = engine.FullBatchGCN
+    if world > 1 and args.backend != "nccl":
+        class HostStagedGather(engine.FullBatchGCN):
+            """Rehearsal only (gloo has no GPU all-gather): stage through the host."""
+
+            def _all_gather(self, out, shard):
+                host = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(host, shard.cpu(), group=self.group)
+                out.copy_(host)
+                return None
+        engine_cls = HostStagedGather
+
+    model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                                 row_begin=rb, n_global=n, seed=seed, group=group, world_size=world,
                                 slab_cols=args.slab_cols or None)
     torch.cuda.synchronize()
@@ -187,8 +216,10 @@ def main():
             dist.barrier(group=group)
         torch.cuda.synchronize()
 
+    note("engine ready")
     for _ in range(args.warmup):
         model.train_step()
+        note("warm-up step done")
     barrier()
     Timed.armed = True
     t0 = time.perf_counter()
@@ -197,6 +228,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     Timed.armed = False
+    note("timed steps done")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

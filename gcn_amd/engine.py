@@ -93,7 +93,6 @@ class FullBatchGCN(object):
         if self.world == 1:
             self.k.spmm(a, src, out=dst, relu=relu)
             return
-        import torch.distributed as dist
         w = src.shape[1]
         slab = min(self.slab, w)
         starts = list(range(0, w, slab))
@@ -105,15 +104,22 @@ class FullBatchGCN(object):
             pk = self.pack[i % 2][:, :nc] if nc == self.slab else self.pack[i % 2].view(-1)[:self.n_loc * nc].view(self.n_loc, nc)
             gb = self.gbuf[i % 2] if nc == self.slab else self.gbuf[i % 2].view(-1)[:self.n * nc].view(self.n, nc)
             pk.copy_(src[:, c0:c0 + nc])
-            works[i] = (dist.all_gather_into_tensor(gb, pk, group=self.group, async_op=True), gb, c0, nc)
+            works[i] = (self._all_gather(gb, pk), gb, c0, nc)
 
         launch(0)
         for i in range(len(starts)):
             if i + 1 < len(starts):
                 launch(i + 1)
             work, gb, c0, nc = works[i]
-            work.wait()
+            if work is not None:
+                work.wait()
             self.k.spmm(a, gb, out=dst[:, c0:c0 + nc], relu=relu)
+
+    def _all_gather(self, out, shard):
+        """Start the all-gather of the row shards into ``out``; returns a work
+        handle (or None when already complete)."""
+        import torch.distributed as dist
+        return dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
 
     def _allreduce(self, t):
         if self.world > 1:
