@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU-baseline slice (0 = skip)")
     ap.add_argument("--slab-cols", type=int, default=0)
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
+    ap.add_argument("--hang-dump", type=int, default=0,
+                    help="with --verbose: dump all Python stacks and exit after this many seconds")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
                     "ranks sharing one GPU)")
     args = ap.parse_args()
@@ -119,6 +121,9 @@ def main():
         if args.verbose:
             print("[rank %d %.1fs] %s" % (rank, time.time() - t_start, msg), file=sys.stderr, flush=True)
 
+    if args.verbose and args.hang_dump:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_dump, exit=True)
     note("process group up (backend %s)" % (args.backend if world > 1 else "none"))
     scale = args.scale or (24 + int(math.log2(world)))
     n = 1 << scale
@@ -141,29 +146,24 @@ def main():
     t_build = time.time()
     a = rmat.rmat_ahat(scale, args.edge_factor, seed, dev, rb, re_, gather_degrees if world > 1 else None)
     note("graph shard built: %d rows, %d nonzeros" % (a.n_rows, a.nnz))
-    nnz_t = torch.tensor([a.nnz], dtype=torch.int64, device=dev)
+    nnz_t = torch.tensor([a.nnz], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(nnz_t, group=group)
     nnz_global = int(nnz_t.item())
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(124 + rank)
-    x = torch.empty((n_loc, args.features), dtype=torch.float32, device=dev)
-    x.uniform_(-1.0, 1.0, generator=gen)
-    gw = torch.Generator(device=dev)
-    gw.manual_seed(125)  # same weights on every rank
+    # features, weights, labels: pure functions of the GLOBAL element index
+    x = ops.philox_uniform((n_loc, args.features), -1.0, 1.0, 124, rb * args.features, dev)
     r1 = math.sqrt(6.0 / (args.features + args.hidden))
     r2 = math.sqrt(6.0 / (args.hidden + args.classes))
-    w1 = (torch.rand((args.features, args.hidden), device=dev, generator=gw) * 2 - 1) * r1
-    w2 = (torch.rand((args.hidden, args.classes), device=dev, generator=gw) * 2 - 1) * r2
-    gl = torch.Generator(device=dev)
-    gl.manual_seed(126 + rank)
-    cls = torch.randint(0, args.classes, (n_loc,), device=dev, generator=gl)
+    w1 = ops.philox_uniform((args.features, args.hidden), -r1, r1, 125, 0, dev)
+    w2 = ops.philox_uniform((args.hidden, args.classes), -r2, r2, 125, 1 << 40, dev)
+    u = ops.philox_uniform((n_loc,), 0.0, float(args.classes), 126, rb, dev)
+    cls = u.to(torch.int64).clamp_(0, args.classes - 1)
     labels = torch.zeros((n_loc, args.classes), dtype=torch.float32, device=dev)
     labels.scatter_(1, cls.view(-1, 1), 1.0)
-    lmask = torch.zeros(n_loc, dtype=torch.uint8, device=dev)
-    lmask[: max(1, n_loc // 100)] = 1          # 1 % of the nodes are labelled
-    mask_total = world * max(1, n_loc // 100)
-    del cls
+    gid = torch.arange(rb, re_, device=dev)
+    lmask = (gid % 100 == 0).to(torch.uint8)      # 1 % of the nodes are labelled
+    mask_total = (n + 99) // 100
+    del cls, u, gid
 
     engine_cls = engine.FullBatchGCN
     if world > 1 and args.backend != "nccl":
@@ -175,6 +175,12 @@ def main():
                 dist.all_gather_into_tensor(host, shard.cpu(), group=self.group)
                 out.copy_(host)
                 return None
+
+            def _allreduce(self, t):
+                host = t.cpu()
+                dist.all_reduce(host, group=self.group)
+                t.copy_(host)
+                return t
         engine_cls = HostStagedGather
 
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
@@ -229,7 +235,7 @@ def main():
     dt = time.perf_counter() - t0
     Timed.armed = False
     note("timed steps done")
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     dt = float(t.item())

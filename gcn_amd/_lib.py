@@ -58,6 +58,7 @@ SIGNATURES = {
                                             _p, _sz, _p]),
     "gcnx_dropout_dense_f32": (_int, [_i64, _p, _p, _f32, _p, _p]),
     "gcnx_bernoulli_mask_u8": (_int, [_i64, _f32, _u64, _u64, _p, _p]),
+    "gcnx_philox_uniform_f32": (_int, [_i64, _f32, _f32, _u64, _u64, _p, _p]),
     "gcnx_dropout_philox_f32": (_int, [_i64, _p, _f32, _u64, _u64, _p, _p, _p]),
     "gcnx_relu_dropout_bwd_philox_f32": (_int, [_i64, _p, _p, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),

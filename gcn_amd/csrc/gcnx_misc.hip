@@ -314,6 +314,26 @@ __global__ __launch_bounds__(kBlock) void dropout_philox_kernel(
   }
 }
 
+// out[i] = lo + (hi - lo) * uniform(seed, offset + i), uniform = (word >> 8) * 2^-24
+__global__ __launch_bounds__(kBlock) void philox_uniform_kernel(int64_t n, float lo, float hi,
+                                                               uint64_t seed, uint64_t offset,
+                                                               float *__restrict__ out) {
+  const uint64_t first_blk = offset >> 2;
+  const uint64_t last_blk = (offset + (uint64_t)n - 1) >> 2;
+  const uint64_t nblk = last_blk - first_blk + 1;
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+       b += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t blk = first_blk + b;
+    const philox4 r = philox4x32_10(blk, 0ull, seed);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t e = blk * 4 + j;
+      if (e >= offset && e < offset + (uint64_t)n)
+        out[e - offset] = lo + (hi - lo) * ((float)(r.v[j] >> 8) * (1.0f / 16777216.0f));
+    }
+  }
+}
+
 __device__ __forceinline__ int64_t row_of_slot2(const int64_t *row_ptr, int64_t n_rows, int64_t s) {
   int64_t lo = 0, hi = n_rows;
   while (hi - lo > 1) {
@@ -460,6 +480,16 @@ extern "C" int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed, uint
   if (n == 0) return GCNX_OK;
   hipLaunchKernelGGL(bernoulli_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
                      as_stream(stream), n, keep, seed, offset, mask);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_philox_uniform_f32(int64_t n, float lo, float hi, uint64_t seed,
+                                       uint64_t offset, float *out, void *stream) {
+  GCNX_REQUIRE(n >= 0 && (n == 0 || out), GCNX_ERR_INVALID_ARG, "philox_uniform: bad argument");
+  if (n == 0) return GCNX_OK;
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
+                     as_stream(stream), n, lo, hi, seed, offset, out);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

@@ -239,6 +239,21 @@ def relu_dropout_bwd(y, dy, mask=None, scale=1.0, out=None):
     return dx
 
 
+def philox_uniform(shape, lo, hi, seed, offset, device):
+    """fp32 tensor of U(lo, hi) values, element i a pure function of
+    (seed, offset + i) (synthetic benchmark inputs)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("philox_uniform needs a CUDA (ROCm) device")
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gcnx_philox_uniform_f32(out.numel(), float(lo), float(hi),
+                                               int(seed) & (2 ** 64 - 1), int(offset), _ptr(out),
+                                               _stream()))
+    return out
+
+
 def dropout_philox(x, keep, seed, offset, out=None, mask_out=None):
     """``out = kept ? x / keep : 0`` with the Bernoulli(keep) mask regenerated
     from Philox (seed, offset + i): same bits as :func:`bernoulli_mask`."""
@@ -313,4 +328,4 @@ def profile_spmm_events(start, stop):
 
 __all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",
            "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
-           "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "adam_step"]
+           "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "philox_uniform", "adam_step"]

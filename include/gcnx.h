@@ -182,6 +182,13 @@ int gcnx_dropout_dense_f32(int64_t n, const float *x, const uint8_t *mask,
 int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed,
                            uint64_t offset, uint8_t *mask, void *stream);
 
+/* Synthetic dense inputs (no counterpart in the reference): out[i] = lo +
+ * (hi - lo) * u(seed, offset + i) with the same Philox uniform as the masks, a
+ * pure function of the global element index, so that features and labels are
+ * the same for every GPU count. */
+int gcnx_philox_uniform_f32(int64_t n, float lo, float hi, uint64_t seed,
+                            uint64_t offset, float *out, void *stream);
+
 /* The same two steps fused, the mask never touching memory: element i is kept
  * iff the Philox uniform of (seed, offset + i) is < keep (bit-identical to
  * gcnx_bernoulli_mask_u8), survivors scaled by 1/keep.  mask_out (nullable)

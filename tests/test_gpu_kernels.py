@@ -297,3 +297,14 @@ def test_dropout_philox_matches_mask_path(env):
         assert np.array_equal(got, np.where(mask != 0, x * np.float32(2.0), np.float32(0)))
         got = env["ops"].relu_dropout_bwd_philox(yt, dyt, 0.5, 247, off).cpu().numpy()
         assert np.array_equal(got, np.where((y > 0) & (mask != 0), dy * np.float32(2.0), np.float32(0)))
+
+
+def test_philox_uniform_matches_oracle(env):
+    for n, off in ((1, 0), (1001, 3), (4096, 1 << 40)):
+        got = env["ops"].philox_uniform((n,), -1.0, 1.0, 124, off, env["dev"]).cpu().numpy()
+        e = np.arange(off, off + n, dtype=np.uint64)
+        r = env["oracle"].philox4x32_10(e >> np.uint64(2), np.uint64(0), 124)
+        w = r[np.arange(n), (e & np.uint64(3)).astype(np.int64)]
+        u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        ref = np.float32(-1.0) + np.float32(2.0) * u
+        assert np.array_equal(got, ref)
