@@ -1,6 +1,6 @@
 """Headline benchmark: full-batch two-layer GCN training steps on a synthetic
-RMAT graph (BASELINE.json config "RMAT 2^24 nodes, avg degree 16, F=256, hidden
-256 full-batch GCN on one MI355X"; with N GPUs the graph grows to
+RMAT graph (the headline configuration: RMAT 2^24 nodes, avg degree 16, F=256, hidden
+256, full-batch GCN on one MI355X; with N GPUs the graph grows to
 2^(24+log2 N) nodes, row-partitioned, fixed 2^24 rows per GPU = weak scaling).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
