@@ -168,12 +168,13 @@ def main():
     engine_cls = engine.FullBatchGCN
     if world > 1 and args.backend != "nccl":
         class HostStagedGather(engine.FullBatchGCN):
-            """Rehearsal only (gloo has no GPU all-gather): stage through the host."""
+            """Rehearsal only (gloo moves host memory): stage collectives through the host."""
 
-            def _all_gather(self, out, shard):
-                host = torch.empty(out.shape, dtype=out.dtype)
-                dist.all_gather_into_tensor(host, shard.cpu(), group=self.group)
-                out.copy_(host)
+            def _all_to_all_start(self, recv, send, recv_counts, send_counts):
+                host = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_to_all_single(host, send.cpu(), output_split_sizes=recv_counts,
+                                       input_split_sizes=send_counts, group=self.group)
+                recv.copy_(host)
                 return None
 
             def _allreduce(self, t):
@@ -184,7 +185,7 @@ def main():
         engine_cls = HostStagedGather
 
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
-                                row_begin=rb, n_global=n, seed=seed, group=group, world_size=world,
+                                row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
                                 slab_cols=args.slab_cols or None)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
@@ -256,6 +257,7 @@ def main():
                             "2-layer GCN, dropout 0.5, Adam" % (scale, scale, 2 * args.edge_factor,
                                                                 args.features, args.hidden, args.classes),
                 "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
+                "halo_rows_rank0": (model.plan.n_halo if model.plan is not None else 0),
                 "spmm_per_step": "2 x width %d + 2 x width %d" % (args.hidden, args.classes),
             },
             "epoch_ms": dt / args.steps * 1e3,

@@ -48,6 +48,11 @@ SIGNATURES = {
     "gcnx_spmm_workspace_bytes": (_sz, [_i64, _i32]),
     "gcnx_spmm_csr_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32,
                                  _int, _p, _sz, _p]),
+    "gcnx_spmm_csr_split_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32,
+                                       _p, _p, _f32, _int, _p, _sz, _p]),
+    "gcnx_halo_plan_workspace_bytes": (_sz, [_i64]),
+    "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
+    "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_profile_spmm_events": (None, [_p, _p]),
     "gcnx_coo_interleave_supports": (_int, [_i32, _p, _p, _p, _i64, _p, _int, _p, _p, _p, _p]),
     "gcnx_gemm_workspace_bytes": (_sz, [_int, _int, _i64, _i64, _i64]),

@@ -199,9 +199,145 @@ static KeyLayout key_layout(int64_t n_keys) {
   return l;
 }
 
+// ---- halo plan -------------------------------------------------------------
+__global__ void halo_mark_kernel(int64_t nnz, const int32_t *__restrict__ col_idx, int64_t lo,
+                                 int64_t hi, int32_t *__restrict__ flag) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const int64_t c = col_idx[s];
+  if (c < lo || c >= hi) flag[c] = 1;  // same value from every writer
+}
+
+__global__ void halo_compact_kernel(int64_t n, const int32_t *__restrict__ flag,
+                                    const int32_t *__restrict__ pos, int64_t cap,
+                                    int32_t *__restrict__ need) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  if (flag[c] && pos[c] < cap) need[pos[c]] = (int32_t)c;
+}
+
+__global__ void halo_remap_kernel(int64_t nnz, const int32_t *__restrict__ col_idx, int64_t lo,
+                                  int64_t hi, const int32_t *__restrict__ pos,
+                                  int32_t *__restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nnz) return;
+  const int64_t c = col_idx[s];
+  out[s] = (c >= lo && c < hi) ? (int32_t)(c - lo) : (int32_t)((hi - lo) + pos[c]);
+}
+
+// one wavefront per 4 rows of 16-byte pieces when aligned, else scalar
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_idx,
+                                                            const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ src,
+                                                            int64_t lds, int32_t width,
+                                                            float *__restrict__ dst, int64_t ldd,
+                                                            int vec) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  const int per_row = vec ? width / 4 : width;
+  const int64_t total = n_idx * (int64_t)per_row;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / per_row;
+    const int q = (int)(e % per_row);
+    const int64_t r = idx[j];
+    if (vec)
+      reinterpret_cast<f4 *>(dst + j * ldd)[q] = reinterpret_cast<const f4 *>(src + r * lds)[q];
+    else
+      dst[j * ldd + q] = src[r * lds + q];
+  }
+}
+
 }  // namespace gcnx
 
 using namespace gcnx;
+
+static size_t halo_scan_temp(int64_t n) {
+  size_t t = 0;
+  int32_t *p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, t, p, p, (int32_t)0, (size_t)(n > 0 ? n : 1),
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
+  return t;
+}
+
+extern "C" size_t gcnx_halo_plan_workspace_bytes(int64_t n_cols_global) {
+  if (n_cols_global < 0) return 0;
+  const size_t n = (size_t)(n_cols_global > 0 ? n_cols_global : 1);
+  return 2 * align_up(n * 4, 256) + align_up(halo_scan_temp(n_cols_global), 256) + 256;
+}
+
+extern "C" int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
+                              int32_t *col_remapped, int32_t *need, int64_t need_cap,
+                              int64_t *h_n_need, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(a && h_n_need && row_begin >= 0 && n_local >= 0 && need_cap >= 0,
+               GCNX_ERR_INVALID_ARG, "halo_plan: bad argument");
+  GCNX_REQUIRE(a->n_cols < INT32_MAX && row_begin + n_local <= a->n_cols, GCNX_ERR_INVALID_ARG,
+               "halo_plan: bad column range");
+  GCNX_REQUIRE(a->nnz == 0 || (a->col_idx && col_remapped), GCNX_ERR_INVALID_ARG,
+               "halo_plan: null array");
+  const size_t needws = gcnx_halo_plan_workspace_bytes(a->n_cols);
+  GCNX_REQUIRE(ws && ws_bytes >= needws, GCNX_ERR_WORKSPACE,
+               "halo_plan: workspace of %zu bytes required, got %zu", needws, ws_bytes);
+  hipStream_t st = as_stream(stream);
+  const int64_t n = a->n_cols;
+  char *w = static_cast<char *>(ws);
+  const size_t arr = align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+  int32_t *flag = reinterpret_cast<int32_t *>(w);
+  int32_t *pos = reinterpret_cast<int32_t *>(w + arr);
+  void *temp = w + 2 * arr;
+  *h_n_need = 0;
+  if (n == 0) return GCNX_OK;
+  GCNX_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)n * 4, st));
+  const int64_t lo = row_begin, hi = row_begin + n_local;
+  if (a->nnz > 0) {
+    hipLaunchKernelGGL(halo_mark_kernel, dim3((unsigned)ceil_div(a->nnz, 256)), dim3(256), 0, st,
+                       a->nnz, a->col_idx, lo, hi, flag);
+    GCNX_CHECK_LAUNCH();
+  }
+  size_t tb = halo_scan_temp(n);
+  GCNX_CHECK_HIP(rocprim::exclusive_scan(temp, tb, flag, pos, (int32_t)0, (size_t)n,
+                                         rocprim::plus<int32_t>(), st));
+  int32_t last_pos = 0, last_flag = 0;
+  GCNX_CHECK_HIP(hipMemcpyAsync(&last_pos, pos + n - 1, 4, hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + n - 1, 4, hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  const int64_t n_need = (int64_t)last_pos + last_flag;
+  *h_n_need = n_need;
+  GCNX_REQUIRE(n_need <= need_cap && (n_need == 0 || need), GCNX_ERR_WORKSPACE,
+               "halo_plan: %lld remote rows referenced but need[] holds %lld", (long long)n_need,
+               (long long)need_cap);
+  GCNX_REQUIRE(n_local + n_need < INT32_MAX, GCNX_ERR_UNSUPPORTED, "halo_plan: too many columns");
+  if (n_need > 0) {
+    hipLaunchKernelGGL(halo_compact_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n,
+                       flag, pos, need_cap, need);
+    GCNX_CHECK_LAUNCH();
+  }
+  if (a->nnz > 0) {
+    hipLaunchKernelGGL(halo_remap_kernel, dim3((unsigned)ceil_div(a->nnz, 256)), dim3(256), 0, st,
+                       a->nnz, a->col_idx, lo, hi, pos, col_remapped);
+    GCNX_CHECK_LAUNCH();
+  }
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
+                                    int64_t lds, int32_t width, float *dst, int64_t ldd,
+                                    void *stream) {
+  GCNX_REQUIRE(n_idx >= 0 && width >= 0, GCNX_ERR_INVALID_ARG, "gather_rows: negative size");
+  if (n_idx == 0 || width == 0) return GCNX_OK;
+  GCNX_REQUIRE(idx && src && dst && lds >= width && ldd >= width, GCNX_ERR_INVALID_ARG,
+               "gather_rows: bad argument");
+  const int vec = (width % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  const int64_t total = n_idx * (int64_t)(vec ? width / 4 : width);
+  int64_t blocks = ceil_div(total, kBlock);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
+                     n_idx, idx, src, lds, width, dst, ldd, vec);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
 
 extern "C" size_t gcnx_csr_from_coo_workspace_bytes(int64_t n_rows, int64_t nnz) {
   if (n_rows < 0 || nnz < 0) return 0;

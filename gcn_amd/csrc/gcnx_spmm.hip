@@ -65,6 +65,9 @@ struct SpmmArgs {
   const int32_t *chunk_row;
   const float *B;
   int64_t ldb;
+  const float *B2;   // rows >= split come from here (halo rows received from peers)
+  int64_t ldb2;
+  int32_t split;     // INT32_MAX when there is no second operand
   float *C;
   int64_t ldc;
   int32_t width;
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(const SpmmArgs a) {
       for (int u = 0; u < U; ++u) {
         const int jj = (j + u) < jn ? (j + u) : (jn - 1);
         const int cc = rl_i(cols, jj);
-        const float *src = a.B + (int64_t)cc * a.ldb + col0;
+        const float *src = (cc < a.split ? a.B + (int64_t)cc * a.ldb
+                                         : a.B2 + (int64_t)(cc - a.split) * a.ldb2) + col0;
         b[u] = V(0.0f);
         if (active) b[u] = vload<VEC>(src);
       }
@@ -307,7 +311,9 @@ __global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
         const float v = __shfl(vals, idc, kWave);
         vv[u] = idx < jn ? v : 0.0f;
         b[u] = V(0.0f);
-        if (active) b[u] = vload<VEC>(a.B + (int64_t)cc * a.ldb + col0);
+        if (active)
+          b[u] = vload<VEC>((cc < a.split ? a.B + (int64_t)cc * a.ldb
+                                          : a.B2 + (int64_t)(cc - a.split) * a.ldb2) + col0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -426,6 +432,17 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
                                  float beta, const uint8_t *val_mask, const int64_t *mask_index,
                                  float mask_scale, int fuse_relu, void *ws, size_t ws_bytes,
                                  void *stream) {
+  return gcnx_spmm_csr_split_f32(a, chunk_row, B, ldb, nullptr, 0, a ? a->n_cols : 0, C, ldc, width,
+                                 alpha, beta, val_mask, mask_index, mask_scale, fuse_relu, ws,
+                                 ws_bytes, stream);
+}
+
+extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
+                                       int64_t ldb, const float *B2, int64_t ldb2,
+                                       int64_t split_col, float *C, int64_t ldc, int32_t width,
+                                       float alpha, float beta, const uint8_t *val_mask,
+                                       const int64_t *mask_index, float mask_scale, int fuse_relu,
+                                       void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(a && C, GCNX_ERR_INVALID_ARG, "spmm: null matrix or output");
   GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
                GCNX_ERR_INVALID_ARG, "spmm: negative size");
@@ -445,6 +462,9 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
   k.chunk_row = chunk_row;
   k.B = B;
   k.ldb = ldb;
+  k.B2 = B2;
+  k.ldb2 = ldb2;
+  k.split = INT32_MAX;
   k.C = C;
   k.ldc = ldc;
   k.width = width;
@@ -466,12 +486,18 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
   GCNX_REQUIRE(a->row_ptr && a->col_idx && a->val && chunk_row && B, GCNX_ERR_INVALID_ARG,
                "spmm: null array");
   GCNX_REQUIRE(ldb >= width, GCNX_ERR_INVALID_ARG, "spmm: ldb < width");
+  if (split_col < a->n_cols) {
+    GCNX_REQUIRE(split_col >= 0 && B2 && ldb2 >= width, GCNX_ERR_INVALID_ARG,
+                 "spmm: second operand missing or ldb2 < width");
+    k.split = (int32_t)split_col;
+  }
   const size_t need = gcnx_spmm_workspace_bytes(a->nnz, width);
   GCNX_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GCNX_ERR_WORKSPACE,
                "spmm: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
   GCNX_REQUIRE(k.n_chunks / kWavesPerBlock < INT32_MAX, GCNX_ERR_UNSUPPORTED, "spmm: too many chunks");
 
-  const bool v4 = (width % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C);
+  const bool v4 = (width % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
+                  (k.split == INT32_MAX || ((ldb2 % 4 == 0) && aligned16(B2)));
   const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
   const int vec = v4 ? 4 : 1;
   const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs

@@ -12,8 +12,9 @@ gcn/metrics.py:4-20, Adam per gcn/models.py:142):
 
 and the backward products  A_hat^T dZ,  H'^T dP2,  dP2 W2^T,  A_hat^T dH,
 X'^T dP1.  With P ranks, rank p owns a contiguous block of rows of A_hat and of
-every activation; the dense operand of each SpMM is assembled by an all-gather
-of the row shards (RCCL over xGMI via torch.distributed), issued in column
+every activation; before each SpMM the rows of the dense operand that the block
+references on other ranks (the halo, gcn_amd/halo.py) are fetched with a
+variable-size all-to-all (RCCL over xGMI via torch.distributed), issued in column
 slabs on the communication stream so that the SpMM of slab s overlaps the
 transfer of slab s+1.  Weight gradients and the loss are all-reduced; Adam runs
 replicated.  Dropout masks are a pure function of (seed, step, global element
@@ -29,8 +30,8 @@ from . import ops as _hip_ops
 class FullBatchGCN(object):
     def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
-                 dropout=0.5, seed=123, group=None, world_size=1, slab_cols=None, kernels=None,
-                 keep_masks=False):
+                 dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
+                 kernels=None, keep_masks=False):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -74,25 +75,33 @@ class FullBatchGCN(object):
         # are only stored when a caller asks for them (keep_masks, for tests)
         self.mask1 = e(nl * self.f, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
         self.mask2 = e(nl * self.h, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
-        # gather buffers (only with more than one rank)
+        # halo exchange (only with more than one rank)
+        self.plan = self.plan_bwd = None
         if self.world > 1:
-            if slab_cols is None:
-                budget = 48 * (1 << 30)        # two slab buffers stay under this
-                slab_cols = self.h
-                while slab_cols > 16 and 2 * self.n * slab_cols * 4 > budget:
-                    slab_cols //= 2
-            self.slab = int(slab_cols)
-            self.gbuf = [e(self.n, self.slab), e(self.n, self.slab)]
-            self.pack = [e(nl, self.slab), e(nl, self.slab)]
+            from .halo import HaloPlan
+            plan_fn = getattr(self.k, "halo_plan", None)
+            kw = {"plan_fn": plan_fn} if plan_fn is not None else {}
+            self.plan = HaloPlan(a_local, self.row_begin, nl, self.world, rank, self._all_to_all, **kw)
+            self.plan_bwd = self.plan if a_bwd_local is None else \
+                HaloPlan(a_bwd_local, self.row_begin, nl, self.world, rank, self._all_to_all, **kw)
+            self.slab = int(slab_cols) if slab_cols else min(64, self.h)
+            n_halo = max(self.plan.n_halo, self.plan_bwd.n_halo, 1)
+            n_send = max(self.plan.n_send, self.plan_bwd.n_send, 1)
+            self.halobuf = [e(n_halo * self.slab), e(n_halo * self.slab)]
+            self.sendbuf = [e(n_send * self.slab), e(n_send * self.slab)]
         else:
             self.slab = None
 
     # ------------------------------------------------------------ collectives
-    def _aggregate(self, a, src, dst, relu):
-        """dst = act(a @ gather_rows(src)); src, dst are [n_loc, W]."""
+    def _aggregate(self, which, src, dst, relu):
+        """dst = act(A @ [src; halo rows of src]) for A = A_hat (which='fwd') or
+        A_hat^T ('bwd'); src, dst are [n_loc, W].  With several ranks the halo
+        rows are fetched in column slabs: the exchange of slab s+1 is in flight
+        on the communication stream while the SpMM of slab s runs."""
         if self.world == 1:
-            self.k.spmm(a, src, out=dst, relu=relu)
+            self.k.spmm(self.a if which == "fwd" else self.at, src, out=dst, relu=relu)
             return
+        plan = self.plan if which == "fwd" else self.plan_bwd
         w = src.shape[1]
         slab = min(self.slab, w)
         starts = list(range(0, w, slab))
@@ -101,25 +110,33 @@ class FullBatchGCN(object):
         def launch(i):
             c0 = starts[i]
             nc = min(slab, w - c0)
-            pk = self.pack[i % 2][:, :nc] if nc == self.slab else self.pack[i % 2].view(-1)[:self.n_loc * nc].view(self.n_loc, nc)
-            gb = self.gbuf[i % 2] if nc == self.slab else self.gbuf[i % 2].view(-1)[:self.n * nc].view(self.n, nc)
-            pk.copy_(src[:, c0:c0 + nc])
-            works[i] = (self._all_gather(gb, pk), gb, c0, nc)
+            sb = self.sendbuf[i % 2][:plan.n_send * nc].view(plan.n_send, nc)
+            hb = self.halobuf[i % 2][:plan.n_halo * nc].view(plan.n_halo, nc)
+            if plan.n_send:
+                self.k.gather_rows(src[:, c0:c0 + nc], plan.send_idx, sb)
+            works[i] = (self._all_to_all_start(hb, sb, plan.recv_counts, plan.send_counts), hb, c0, nc)
 
         launch(0)
         for i in range(len(starts)):
             if i + 1 < len(starts):
                 launch(i + 1)
-            work, gb, c0, nc = works[i]
+            work, hb, c0, nc = works[i]
             if work is not None:
                 work.wait()
-            self.k.spmm(a, gb, out=dst[:, c0:c0 + nc], relu=relu)
+            self.k.spmm(plan.csr, src[:, c0:c0 + nc], out=dst[:, c0:c0 + nc], relu=relu,
+                        b2=hb if plan.n_halo else None)
 
-    def _all_gather(self, out, shard):
-        """Start the all-gather of the row shards into ``out``; returns a work
-        handle (or None when already complete)."""
+    def _all_to_all_start(self, recv, send, recv_counts, send_counts):
+        """Start the variable-size all-to-all (rows of dim 0); returns a work
+        handle or None when it has already completed."""
         import torch.distributed as dist
-        return dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
+        return dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
+                                      input_split_sizes=send_counts, group=self.group, async_op=True)
+
+    def _all_to_all(self, recv, send, recv_counts, send_counts):
+        work = self._all_to_all_start(recv, send, recv_counts, send_counts)
+        if work is not None:
+            work.wait()
 
     def _allreduce(self, t):
         if self.world > 1:
@@ -139,7 +156,7 @@ class FullBatchGCN(object):
         else:
             xin = self.x
         k.gemm(xin, self.w1, out=self.p1)
-        self._aggregate(self.a, self.p1, self.hb, relu=True)
+        self._aggregate("fwd", self.p1, self.hb, relu=True)
         if keep < 1.0:
             k.dropout_philox(self.hb.view(-1), keep, self.seed * 2 + 2, off + self.row_begin * self.h,
                              out=self.hd.view(-1), mask_out=self.mask2)
@@ -147,7 +164,7 @@ class FullBatchGCN(object):
         else:
             hin = self.hb
         k.gemm(hin, self.w2, out=self.p2)
-        self._aggregate(self.a, self.p2, self.z, relu=False)
+        self._aggregate("fwd", self.p2, self.z, relu=False)
         return xin, hin
 
     def loss(self, want_grad):
@@ -164,7 +181,7 @@ class FullBatchGCN(object):
         out = self.loss(want_grad=True)
         keep = self.keep
         # layer 2
-        self._aggregate(self.at, self.dz, self.dp2, relu=False)            # A^T dZ
+        self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1)                # dP2 W2^T -> dH'
         if keep < 1.0:
@@ -175,7 +192,7 @@ class FullBatchGCN(object):
             k.relu_dropout_bwd(self.hb.view(-1), self.p1.view(-1), None, 1.0, out=self.hd.view(-1))
         # hd now holds d(A P1)
         # layer 1
-        self._aggregate(self.at, self.hd, self.hb, relu=False)             # A^T dH -> dP1
+        self._aggregate("bwd", self.hd, self.hb, relu=False)             # A^T dH -> dP1
         k.gemm(xin, self.hb, trans_a=True, out=self.g1)                     # X'^T dP1
         self._allreduce(self.g1)
         self._allreduce(self.g2)

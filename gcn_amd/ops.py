@@ -22,15 +22,23 @@ def _check_dense(t, name):
 
 
 # ------------------------------------------------------------------------ SpMM
-def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False):
+def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False, b2=None):
     """``out = act(alpha * A' @ b + beta * out)`` with ``A`` a :class:`Csr`.
     ``mask`` (uint8, in the order of the tuple ``A`` was built from) applies
     sparse dropout to the values on the fly.  Replaces ``dot(x, y, sparse=True)``
-    (reference gcn/layers.py:30-33) and ``sparse_dropout`` (:21-27)."""
+    (reference gcn/layers.py:30-33) and ``sparse_dropout`` (:21-27).
+    With ``b2`` the dense operand is the row-wise concatenation ``[b; b2]``
+    without being assembled (local rows + halo rows of a partitioned run)."""
     lib = _lib.load()
     _check_dense(b, "b")
-    if b.shape[0] != a.n_cols:
-        raise ValueError("shape mismatch: A is %s, b is %s" % (a.shape, tuple(b.shape)))
+    rows_b2 = 0
+    if b2 is not None:
+        _check_dense(b2, "b2")
+        if b2.shape[1] != b.shape[1] or b2.device != b.device:
+            raise ValueError("b and b2 differ in width or device")
+        rows_b2 = b2.shape[0]
+    if b.shape[0] + rows_b2 != a.n_cols:
+        raise ValueError("shape mismatch: A is %s, operand has %d rows" % (a.shape, b.shape[0] + rows_b2))
     if b.device != a.device:
         raise ValueError("A and b live on different devices")
     width = b.shape[1]
@@ -50,10 +58,11 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
     with torch.cuda.device(a.device):
         need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
         ws = WORKSPACE.get(need, a.device)
-        _lib.check(lib.gcnx_spmm_csr_f32(
-            a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
-            width, float(alpha), float(beta), _ptr(mask), _ptr(midx), float(mask_scale),
-            1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+        _lib.check(lib.gcnx_spmm_csr_split_f32(
+            a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
+            _ptr(b2 if rows_b2 else None), b2.stride(0) if rows_b2 else 0, b.shape[0],
+            _ptr(out), out.stride(0), width, float(alpha), float(beta), _ptr(mask), _ptr(midx),
+            float(mask_scale), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
     return out
 
 
@@ -239,6 +248,21 @@ def relu_dropout_bwd(y, dy, mask=None, scale=1.0, out=None):
     return dx
 
 
+def gather_rows(src, idx, out):
+    """``out[j, :] = src[idx[j], :]`` (``idx`` int32 on the device)."""
+    lib = _lib.load()
+    _check_dense(src, "src")
+    _check_dense(out, "out")
+    if idx.dtype != torch.int32 or idx.device != src.device or not idx.is_contiguous():
+        raise ValueError("idx must be a contiguous int32 tensor on src's device")
+    if out.shape[0] != idx.numel() or out.shape[1] != src.shape[1]:
+        raise ValueError("out must be [len(idx), width]")
+    with torch.cuda.device(src.device):
+        _lib.check(lib.gcnx_gather_rows_f32(idx.numel(), _ptr(idx), _ptr(src), src.stride(0),
+                                            src.shape[1], _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 def philox_uniform(shape, lo, hi, seed, offset, device):
     """fp32 tensor of U(lo, hi) values, element i a pure function of
     (seed, offset + i) (synthetic benchmark inputs)."""
@@ -328,4 +352,4 @@ def profile_spmm_events(start, stop):
 
 __all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",
            "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
-           "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "philox_uniform", "adam_step"]
+           "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "philox_uniform", "gather_rows", "adam_step"]

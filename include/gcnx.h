@@ -116,6 +116,39 @@ int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       float mask_scale, int fuse_relu, void *ws,
                       size_t ws_bytes, void *stream);
 
+/* The same product with the dense operand in two pieces: rows [0, split_col) of
+ * the operand are read from B, rows [split_col, n_cols) from B2 (row 0 of B2 is
+ * operand row split_col).  Used by the row-partitioned engine: B holds the
+ * local rows of the activation, B2 the halo rows received from the other GPUs,
+ * so no combined copy is ever assembled.  No counterpart in the reference
+ * (single process). */
+int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                            const float *B, int64_t ldb, const float *B2,
+                            int64_t ldb2, int64_t split_col, float *C,
+                            int64_t ldc, int32_t width, float alpha, float beta,
+                            const uint8_t *val_mask, const int64_t *mask_index,
+                            float mask_scale, int fuse_relu, void *ws,
+                            size_t ws_bytes, void *stream);
+
+/* ---- halo exchange of a row-partitioned graph (no counterpart in the
+ * reference, which is single-process) ---------------------------------------
+ * gcnx_halo_plan: `a` holds local rows [row_begin, row_begin + n_local) with
+ * GLOBAL column ids.  Writes (1) need[]: the sorted list of the distinct
+ * global columns outside the local range that the shard references (*h_n_need
+ * of them; they are the rows to fetch from their owners), and (2)
+ * col_remapped[slot]: local columns become c - row_begin, remote ones
+ * n_local + position in need[].  GCNX_ERR_WORKSPACE if need_cap is too small
+ * (*h_n_need then holds the required size).
+ * gcnx_gather_rows_f32: dst[j, 0:width] = src[idx[j], 0:width] (packs the rows
+ * a peer asked for into a contiguous send buffer). */
+size_t gcnx_halo_plan_workspace_bytes(int64_t n_cols_global);
+int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
+                   int32_t *col_remapped, int32_t *need, int64_t need_cap,
+                   int64_t *h_n_need, void *ws, size_t ws_bytes, void *stream);
+int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
+                         int64_t lds, int32_t width, float *dst, int64_t ldd,
+                         void *stream);
+
 /* Measurement hook (no counterpart in the reference): while set, every
  * gcnx_spmm_csr_f32 call made by this thread records hipEvent `start` right
  * before and `stop` right after its main kernel, on the launch stream, so a

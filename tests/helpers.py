@@ -70,7 +70,25 @@ class OracleKernels(object):
         import oracle
         self.torch, self.o = torch, oracle
 
-    def spmm(self, a, b, out=None, relu=False, **kw):
+    def halo_plan(self, a, row_begin, n_loc):
+        """numpy counterpart of gcn_amd.halo.device_halo_plan."""
+        import copy
+        c = a.col_idx.astype(np.int64)
+        local = (c >= row_begin) & (c < row_begin + n_loc)
+        need = np.unique(c[~local])
+        new = np.where(local, c - row_begin, n_loc + np.searchsorted(need, c))
+        out = copy.copy(a)
+        out.col_idx = new.astype(np.int32)
+        out.n_cols = int(n_loc + len(need))
+        return out, self.torch.from_numpy(need.astype(np.int32))
+
+    def gather_rows(self, src, idx, out):
+        out.copy_(src[idx.long()])
+        return out
+
+    def spmm(self, a, b, out=None, relu=False, b2=None, **kw):
+        if b2 is not None:
+            b = self.torch.cat([b, b2], 0)
         r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
         if relu:
             r = np.maximum(r, 0)

@@ -1,7 +1,7 @@
 """world_size-2 tests of the row-partitioned engine on the gloo backend (CPU).
 The kernels are answered by the oracle (tests/helpers.OracleKernels); what is
-under test is the partition, the slabbed all-gather of the dense operand, the
-all-reduce of weight gradients / loss, and the rule that dropout masks depend on
+under test is the partition, the halo plan and the slabbed halo all-to-all of the dense
+operand, the all-reduce of weight gradients / loss, and the rule that dropout masks depend on
 the global element index only, so that 1-rank and 2-rank runs agree."""
 import os
 import socket
@@ -44,7 +44,7 @@ def _run(rank, world, port, slab, out_dir):
     eng = engine.FullBatchGCN(
         CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
         int(lmask.sum()), hidden, classes, T(w1), T(w2), row_begin=rb, n_global=n, seed=5,
-        group=dist.group.WORLD if world > 1 else None, world_size=world, slab_cols=slab,
+        group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank, slab_cols=slab,
         kernels=OracleKernels())
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
     ev = eng.evaluate().numpy().copy()
@@ -63,14 +63,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("slab", [16, 8])
-def test_two_ranks_match_one_rank(tmp_path, slab):
+@pytest.mark.parametrize("world,slab", [(2, 16), (2, 8), (4, 4)])
+def test_ranks_match_one_rank(tmp_path, world, slab):
     out = str(tmp_path)
     _run(0, 1, 0, None, out)
-    mp.spawn(_run, args=(2, _free_port(), slab, out), nprocs=2, join=True)
+    mp.spawn(_run, args=(world, _free_port(), slab, out), nprocs=world, join=True)
     one = np.load(os.path.join(out, "w1_r0.npz"))
-    r0 = np.load(os.path.join(out, "w2_r0.npz"))
-    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    r0 = np.load(os.path.join(out, "w%d_r0.npz" % world))
+    r1 = np.load(os.path.join(out, "w%d_r1.npz" % world))
     # replicated state is identical on both ranks
     assert np.array_equal(r0["w1"], r1["w1"]) and np.array_equal(r0["w2"], r1["w2"])
     assert np.array_equal(r0["outs"], r1["outs"])
@@ -79,7 +79,7 @@ def test_two_ranks_match_one_rank(tmp_path, slab):
     np.testing.assert_allclose(r0["ev"], one["ev"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(r0["w1"], one["w1"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
-    z = np.concatenate([r0["z"], r1["z"]])
+    z = np.concatenate([np.load(os.path.join(out, "w%d_r%d.npz" % (world, r)))["z"] for r in range(world)])
     np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
 
 

@@ -308,3 +308,46 @@ def test_philox_uniform_matches_oracle(env):
         u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
         ref = np.float32(-1.0) + np.float32(2.0) * u
         assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("width", [7, 16, 64, 256])
+def test_spmm_split_operand_bitwise(env, width):
+    """[b; b2] read in place equals the assembled operand, bit for bit."""
+    torch = env["torch"]
+    a, b, rp, ci, v, _, _ = _spmm_case(env, 3000, 2500, 50000, width, hub=[(9, 4000)], seed=21)
+    bt = torch.from_numpy(b).to(env["dev"])
+    full = env["ops"].spmm(a, bt, relu=True)
+    for n1 in (0, 1, 1000, 2499):
+        top = bt[:n1] if n1 else bt[:0]
+        got = env["ops"].spmm(a, top.contiguous() if n1 else torch.empty((0, width), device=env["dev"]),
+                              b2=bt[n1:].contiguous(), relu=True)
+        assert torch.equal(full, got), n1
+
+
+def test_halo_plan_and_gather_rows(env):
+    from gcn_amd import halo
+    torch = env["torch"]
+    rng = np.random.RandomState(31)
+    n, n_loc, rb = 4000, 1000, 2000
+    rows, cols, vals = random_coo(rng, n_loc, n, 30000)
+    a = env["sparse"].Csr.from_coo(rows, cols, vals, (n_loc, n), env["dev"])
+    csr, need = halo.device_halo_plan(a, rb, n_loc)
+    c = a.col_idx.cpu().numpy().astype(np.int64)
+    local = (c >= rb) & (c < rb + n_loc)
+    need_ref = np.unique(c[~local])
+    new_ref = np.where(local, c - rb, n_loc + np.searchsorted(need_ref, c))
+    assert np.array_equal(need.cpu().numpy(), need_ref.astype(np.int32))
+    assert np.array_equal(csr.col_idx.cpu().numpy(), new_ref.astype(np.int32))
+    assert csr.n_cols == n_loc + len(need_ref)
+    # product through [local | halo] equals the product with global columns
+    b = torch.from_numpy(rng.standard_normal((n, 64)).astype(np.float32)).to(env["dev"])
+    ref = env["ops"].spmm(a, b)
+    hal = torch.empty((len(need_ref), 64), device=env["dev"])
+    env["ops"].gather_rows(b, need, hal)
+    assert torch.equal(hal, b[need.long()])
+    got = env["ops"].spmm(csr, b[rb:rb + n_loc].contiguous(), b2=hal)
+    assert torch.equal(ref, got)
+    # strided source view (a column slab) and odd widths
+    sub = torch.empty((len(need_ref), 7), device=env["dev"])
+    env["ops"].gather_rows(b[:, 3:10], need, sub)
+    assert torch.equal(sub, b[need.long(), 3:10])
