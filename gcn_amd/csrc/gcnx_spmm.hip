@@ -483,8 +483,8 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
     GCNX_CHECK_LAUNCH();
     return GCNX_OK;
   }
-  GCNX_REQUIRE(a->row_ptr && a->col_idx && a->val && chunk_row && B, GCNX_ERR_INVALID_ARG,
-               "spmm: null array");
+  GCNX_REQUIRE(a->row_ptr && a->col_idx && a->val && chunk_row && (B || split_col == 0),
+               GCNX_ERR_INVALID_ARG, "spmm: null array");
   GCNX_REQUIRE(ldb >= width, GCNX_ERR_INVALID_ARG, "spmm: ldb < width");
   if (split_col < a->n_cols) {
     GCNX_REQUIRE(split_col >= 0 && B2 && ldb2 >= width, GCNX_ERR_INVALID_ARG,
