@@ -128,21 +128,29 @@ __global__ __launch_bounds__(kBlock) void gemm_reduce_kernel(const GemmArgs g) {
 typedef float __attribute__((ext_vector_type(16))) f16v;
 typedef float __attribute__((ext_vector_type(4))) f4v;
 
-constexpr int MB = 128, NB = 128, KB = 16;
+constexpr int MB = 128, KB = 16;
 
+// BN = 128: wavefront w owns rows [32w, 32w+32) and all 128 columns (four
+// accumulator tiles).  BN = 32: the class-dimension / skinny case (N <= 32,
+// columns beyond N read as zero, one tile per wavefront); such products are
+// bound by streaming A (or writing C), the matrix pipe has room to spare.
+// TB: B is stored [N, K] (the product with a transposed weight matrix); it is
+// transposed while it is staged, so the inner loop is the same.
+template <int BN, bool TB>
 __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
   // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
   // stride-17 words (conflict free), lanes 32..63 the next k.
+  constexpr int NT = BN / 32;
   __shared__ float As[MB * (KB + 1)];
-  __shared__ float Bs[KB * NB];
+  __shared__ float Bs[KB * BN];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * MB;
-  const int64_t n0 = (int64_t)blockIdx.y * NB;
-  f16v acc[NB / 32];
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  f16v acc[NT];
 #pragma unroll
-  for (int t = 0; t < NB / 32; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
@@ -159,35 +167,58 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
       float *d = As + m * (KB + 1) + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    // B: 16 rows x 128 floats = 512 float4, two per thread
+    if constexpr (!TB && BN == 128) {
+      // B: 16 rows x 128 floats = 512 float4, two per thread
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * kBlock;
-      const int k = e >> 5, q = e & 31;
-      const f4v v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
-      *reinterpret_cast<f4v *>(Bs + k * NB + q * 4) = v;
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e >> 5, q = e & 31;
+        const f4v v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = v;
+      }
+    } else if constexpr (!TB) {
+#pragma unroll
+      for (int i = 0; i < (KB * BN) / kBlock; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e / BN, n = e % BN;
+        Bs[k * BN + n] = (n0 + n < g.N) ? g.B[(kk + k) * g.ldb + n0 + n] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < (KB * BN) / kBlock; ++i) {
+        const int e = tid + i * kBlock;
+        const int n = e / KB, k = e % KB;
+        Bs[k * BN + n] = (n0 + n < g.N) ? g.B[(n0 + n) * g.ldb + kk + k] : 0.0f;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int k2 = 0; k2 < KB; k2 += 2) {
-      const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
+      if constexpr (BN == 128) {
+        const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
 #pragma unroll
-      for (int t = 0; t < NB / 32; ++t) {
-        const float b = Bs[(k2 + lk) * NB + t * 32 + li];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+          const float b = Bs[(k2 + lk) * BN + t * 32 + li];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      } else {
+        const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
+        const float b = Bs[(k2 + lk) * BN + li];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
       }
     }
     __syncthreads();
   }
   // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
-  for (int t = 0; t < NB / 32; ++t) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int rgi = 0; rgi < 16; ++rgi) {
       const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
       const int64_t gm = m0 + w * 32 + row;
-      if (gm >= g.M) continue;
-      float *dst = g.C + gm * g.ldc + n0 + t * 32 + li;
+      const int64_t gn = n0 + t * 32 + li;
+      if (gm >= g.M || gn >= g.N) continue;
+      float *dst = g.C + gm * g.ldc + gn;
       float out = g.alpha * acc[t][rgi];
       if (g.beta != 0.0f) out += g.beta * *dst;
       if (g.relu) out = fmaxf(out, 0.0f);
@@ -359,14 +390,23 @@ extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
   g.alpha = alpha; g.beta = beta; g.relu = fuse_relu;
   g.partial = nullptr; g.splits = 1; g.k_per_split = K > 0 ? K : 1;
 
-  const bool mfma_ok = !trans_a && !trans_b && N >= 64 && K >= 64 && (N % NB == 0) &&
-                       (K % KB == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && aligned16(A) &&
-                       aligned16(B) && M >= 4 * MB;
+  // MFMA for tall products once a weight dimension reaches 64 (hidden >= 64);
+  // narrower layers stay on the VALU kernel.
+  const bool mfma_ok = !trans_a && M >= 4 * MB && (K % KB == 0) && (N >= 64 || K >= 64) &&
+                       (N % 128 == 0 || N <= 32) && (lda % 4 == 0) && aligned16(A) &&
+                       (trans_b || N <= 32 || ((ldb % 4 == 0) && aligned16(B)));
   if (mfma_ok) {
     // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
     const int64_t mt = ceil_div(M, MB);
-    GCNX_REQUIRE(mt <= 0x7fffffffll && N / NB <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
-    hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)mt, (unsigned)(N / NB)), dim3(kBlock), 0, st, g);
+    GCNX_REQUIRE(mt <= 0x7fffffffll && N / 128 <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
+    const dim3 grid((unsigned)mt, (unsigned)(N % 128 == 0 ? N / 128 : 1));
+    if (N % 128 == 0) {
+      if (trans_b) hipLaunchKernelGGL((gemm_mfma_kernel<128, true>), grid, dim3(kBlock), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<128, false>), grid, dim3(kBlock), 0, st, g);
+    } else {
+      if (trans_b) hipLaunchKernelGGL((gemm_mfma_kernel<32, true>), grid, dim3(kBlock), 0, st, g);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<32, false>), grid, dim3(kBlock), 0, st, g);
+    }
     GCNX_CHECK_LAUNCH();
     return GCNX_OK;
   }

@@ -194,6 +194,7 @@ def test_spmm_reproducible_and_strided(env):
     (0, 0, 700, 128, 64), (0, 0, 513, 100, 37), (0, 1, 2708, 16, 7), (0, 1, 3000, 256, 16),
     (1, 0, 16, 7, 2708), (1, 0, 256, 16, 100000), (1, 0, 256, 256, 20000), (1, 1, 33, 21, 65),
     (1, 0, 128, 7, 5000), (1, 0, 384, 128, 9999), (1, 0, 256, 32, 4100),
+    (0, 0, 5000, 16, 256), (0, 0, 5001, 7, 64), (0, 1, 5000, 256, 16), (0, 1, 777, 128, 64), (0, 1, 4096, 20, 128),
 ])
 def test_gemm_matches_oracle(env, ta, tb, M, N, K):
     torch = env["torch"]
