@@ -24,6 +24,12 @@ class GcnxError(RuntimeError):
         self.code = code
 
 
+class DropoutStruct(C.Structure):
+    """Mirror of ``struct gcnx_dropout``."""
+    _fields_ = [("keep", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("ld", C.c_int64), ("col0", C.c_int64)]
+
+
 class CsrStruct(C.Structure):
     """Mirror of ``struct gcnx_csr``."""
     _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64),
@@ -49,7 +55,9 @@ SIGNATURES = {
     "gcnx_spmm_csr_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32,
                                  _int, _p, _sz, _p]),
     "gcnx_spmm_csr_split_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32,
-                                       _p, _p, _f32, _int, _p, _sz, _p]),
+                                       _p, _p, _f32, _int, _p, _p, _sz, _p]),
+    "gcnx_gemm_gated_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _f32,
+                                   _f32, _p, _i64, _f32, _p, _sz, _p]),
     "gcnx_halo_plan_workspace_bytes": (_sz, [_i64]),
     "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
     "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),

@@ -30,7 +30,19 @@ struct GemmArgs {
   float *partial;  // [splits][M][N] when splits > 1
   int64_t k_per_split;
   int splits;
+  const float *gate;   // nullable: out = gate > 0 ? out * gate_scale : 0
+  int64_t ldgate;
+  float gate_scale;
 };
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs &g, float acc, float *dst, int64_t gm,
+                                               int64_t gn) {
+  float out = g.alpha * acc;
+  if (g.beta != 0.0f) out += g.beta * *dst;
+  if (g.relu) out = fmaxf(out, 0.0f);
+  if (g.gate) out = g.gate[gm * g.ldgate + gn] > 0.0f ? out * g.gate_scale : 0.0f;
+  return out;
+}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(kBlock) void gemm_tile_kernel(const GemmArgs g) {
@@ -96,10 +108,7 @@ __global__ __launch_bounds__(kBlock) void gemm_tile_kernel(const GemmArgs g) {
         g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[i][j];
       } else {
         float *dst = g.C + gm * g.ldc + gn;
-        float out = g.alpha * acc[i][j];
-        if (g.beta != 0.0f) out += g.beta * *dst;
-        if (g.relu) out = fmaxf(out, 0.0f);
-        *dst = out;
+        *dst = gemm_epilogue(g, acc[i][j], dst, gm, gn);
       }
     }
   }
@@ -111,10 +120,7 @@ __global__ __launch_bounds__(kBlock) void gemm_reduce_kernel(const GemmArgs g) {
   float s = 0.0f;
   for (int z = 0; z < g.splits; ++z) s += g.partial[(int64_t)z * g.M * g.N + e];
   float *dst = g.C + (e / g.N) * g.ldc + (e % g.N);
-  float out = g.alpha * s;
-  if (g.beta != 0.0f) out += g.beta * *dst;
-  if (g.relu) out = fmaxf(out, 0.0f);
-  *dst = out;
+  *dst = gemm_epilogue(g, s, dst, e / g.N, e % g.N);
 }
 
 // ---------------------------------------------------------------------------
@@ -137,7 +143,7 @@ constexpr int MB = 128, KB = 16;
 // TB: B is stored [N, K] (the product with a transposed weight matrix); it is
 // transposed while it is staged, so the inner loop is the same.
 template <int BN, bool TB>
-__global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) {
   // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
   // stride-17 words (conflict free), lanes 32..63 the next k.
   constexpr int NT = BN / 32;
@@ -219,10 +225,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
       const int64_t gn = n0 + t * 32 + li;
       if (gm >= g.M || gn >= g.N) continue;
       float *dst = g.C + gm * g.ldc + gn;
-      float out = g.alpha * acc[t][rgi];
-      if (g.beta != 0.0f) out += g.beta * *dst;
-      if (g.relu) out = fmaxf(out, 0.0f);
-      *dst = out;
+      *dst = gemm_epilogue(g, acc[t][rgi], dst, gm, gn);
     }
   }
 }
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_kernel(const GemmArgs g) {
 // splits in order.
 // ---------------------------------------------------------------------------
 template <int BN>
-__global__ __launch_bounds__(kBlock) void gemm_mfma_tn_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs g) {
   constexpr int BM = 128, BK = 16;
   constexpr int WN = BN == 128 ? 2 : 1;          // wavefronts along N
   constexpr int WM = 4 / WN;                     // wavefronts along M
@@ -324,10 +327,7 @@ __global__ __launch_bounds__(kBlock) void gemm_mfma_tn_kernel(const GemmArgs g) 
           g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[a][b][rgi];
         } else {
           float *dst = g.C + gm * g.ldc + gn;
-          float out = g.alpha * acc[a][b][rgi];
-          if (g.beta != 0.0f) out += g.beta * *dst;
-          if (g.relu) out = fmaxf(out, 0.0f);
-          *dst = out;
+          *dst = gemm_epilogue(g, acc[a][b][rgi], dst, gm, gn);
         }
       }
 }
@@ -373,10 +373,33 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
+                     int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
+                     float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
+                     void *ws, size_t ws_bytes, void *stream);
+
 extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                              const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                              int64_t ldc, float alpha, float beta, int fuse_relu, void *ws,
                              size_t ws_bytes, void *stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr,
+                   0, 1.0f, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                   const float *A, int64_t lda, const float *B, int64_t ldb,
+                                   float *C, int64_t ldc, float alpha, float beta,
+                                   const float *gate, int64_t ldgate, float gate_scale, void *ws,
+                                   size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(gate && ldgate >= N, GCNX_ERR_INVALID_ARG, "gemm_gated: bad gate");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, gate, ldgate,
+                   gate_scale, ws, ws_bytes, stream);
+}
+
+static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
+                     int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
+                     float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
+                     void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
   if (M == 0 || N == 0) return GCNX_OK;
   GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
@@ -389,6 +412,7 @@ extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta; g.relu = fuse_relu;
   g.partial = nullptr; g.splits = 1; g.k_per_split = K > 0 ? K : 1;
+  g.gate = gate; g.ldgate = ldgate; g.gate_scale = gate_scale;
 
   // MFMA for tall products once a weight dimension reaches 64 (hidden >= 64);
   // narrower layers stay on the VALU kernel.

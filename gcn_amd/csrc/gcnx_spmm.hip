@@ -18,6 +18,7 @@
 // on); spmm_fixup_kernel adds them in chunk order and applies the epilogue, so
 // the result does not depend on scheduling.
 #include "gcnx_common.h"
+#include "gcnx_philox.h"
 
 namespace gcnx {
 
@@ -79,6 +80,13 @@ struct SpmmArgs {
   float mscale;
   int relu;
   float *partial;
+  // dropout fused behind the activation (keep >= 1: off).  Element (r, col) of
+  // the output has global index drop_offset + r * drop_ld + drop_col0 + col.
+  float drop_keep;
+  uint64_t drop_seed;
+  uint64_t drop_offset;
+  int64_t drop_ld;
+  int64_t drop_col0;
 };
 
 template <int VEC>
@@ -88,6 +96,20 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &a, int64_t r, int
   typename vec_of<VEC>::type out = acc * a.alpha;
   if (a.beta != 0.0f) out += vload<VEC>(dst) * a.beta;
   if (a.relu) out = vmax0<VEC>(out);
+  if (a.drop_keep < 1.0f) {
+    const uint64_t e0 = a.drop_offset + (uint64_t)r * (uint64_t)a.drop_ld + (uint64_t)(a.drop_col0 + col0);
+    const float inv = 1.0f / a.drop_keep;
+    if constexpr (VEC == 4) {
+      // the host checked that e0 is a multiple of 4: one Philox block per store
+      const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, a.drop_seed);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        out[i] = ((float)(rnd.v[i] >> 8) * (1.0f / 16777216.0f) < a.drop_keep) ? out[i] * inv : 0.0f;
+    } else {
+      const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, a.drop_seed);
+      out = ((float)(rnd.v[e0 & 3] >> 8) * (1.0f / 16777216.0f) < a.drop_keep) ? out * inv : 0.0f;
+    }
+  }
   vstore<VEC>(dst, out);
 }
 
@@ -370,6 +392,12 @@ __global__ void spmm_empty_kernel(const SpmmArgs a) {
   float *dst = a.C + (i / a.width) * a.ldc + (i % a.width);
   float out = a.beta != 0.0f ? *dst * a.beta : 0.0f;
   if (a.relu) out = fmaxf(out, 0.0f);
+  if (a.drop_keep < 1.0f) {
+    const uint64_t e0 = a.drop_offset + (uint64_t)(i / a.width) * (uint64_t)a.drop_ld +
+                        (uint64_t)(a.drop_col0 + (i % a.width));
+    const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, a.drop_seed);
+    out = ((float)(rnd.v[e0 & 3] >> 8) * (1.0f / 16777216.0f) < a.drop_keep) ? out / a.drop_keep : 0.0f;
+  }
   *dst = out;
 }
 
@@ -433,8 +461,8 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
                                  float mask_scale, int fuse_relu, void *ws, size_t ws_bytes,
                                  void *stream) {
   return gcnx_spmm_csr_split_f32(a, chunk_row, B, ldb, nullptr, 0, a ? a->n_cols : 0, C, ldc, width,
-                                 alpha, beta, val_mask, mask_index, mask_scale, fuse_relu, ws,
-                                 ws_bytes, stream);
+                                 alpha, beta, val_mask, mask_index, mask_scale, fuse_relu, nullptr,
+                                 ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
@@ -442,7 +470,8 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
                                        int64_t split_col, float *C, int64_t ldc, int32_t width,
                                        float alpha, float beta, const uint8_t *val_mask,
                                        const int64_t *mask_index, float mask_scale, int fuse_relu,
-                                       void *ws, size_t ws_bytes, void *stream) {
+                                       const gcnx_dropout *out_dropout, void *ws, size_t ws_bytes,
+                                       void *stream) {
   GCNX_REQUIRE(a && C, GCNX_ERR_INVALID_ARG, "spmm: null matrix or output");
   GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
                GCNX_ERR_INVALID_ARG, "spmm: negative size");
@@ -476,6 +505,22 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   k.mscale = mask_scale;
   k.relu = fuse_relu;
   k.partial = static_cast<float *>(ws);
+  k.drop_keep = 1.0f;
+  k.drop_seed = 0;
+  k.drop_offset = 0;
+  k.drop_ld = 0;
+  k.drop_col0 = 0;
+  bool drop_vec_ok = true;
+  if (out_dropout && out_dropout->keep < 1.0f) {
+    GCNX_REQUIRE(out_dropout->keep > 0.0f && out_dropout->ld >= width && out_dropout->col0 >= 0,
+                 GCNX_ERR_INVALID_ARG, "spmm: bad output dropout descriptor");
+    k.drop_keep = out_dropout->keep;
+    k.drop_seed = out_dropout->seed;
+    k.drop_offset = out_dropout->offset;
+    k.drop_ld = out_dropout->ld;
+    k.drop_col0 = out_dropout->col0;
+    drop_vec_ok = (out_dropout->offset % 4 == 0) && (out_dropout->ld % 4 == 0) && (out_dropout->col0 % 4 == 0);
+  }
 
   if (a->nnz == 0) {
     const int64_t total = a->n_rows * (int64_t)width;
@@ -497,7 +542,7 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   GCNX_REQUIRE(k.n_chunks / kWavesPerBlock < INT32_MAX, GCNX_ERR_UNSUPPORTED, "spmm: too many chunks");
 
   const bool v4 = (width % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C) &&
-                  (k.split == INT32_MAX || ((ldb2 % 4 == 0) && aligned16(B2)));
+                  (k.split == INT32_MAX || ((ldb2 % 4 == 0) && aligned16(B2))) && drop_vec_ok;
   const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
   const int vec = v4 ? 4 : 1;
   const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs

@@ -63,9 +63,9 @@ class FullBatchGCN(object):
         nl = self.n_loc
         # activations / gradients of the local rows, allocated once
         self.xd = e(nl, self.f)        # dropout(X)
-        self.p1 = e(nl, self.h)        # X' W1; later dP2 W2^T (gradient wrt H')
-        self.hb = e(nl, self.h)        # relu(A P1); later A^T dH (gradient wrt P1)
-        self.hd = e(nl, self.h)        # dropout(H)
+        self.p1 = e(nl, self.h)        # X' W1; later the gradient wrt A P1
+        self.hb = e(nl, self.h)        # A^T dH (gradient wrt P1)
+        self.hd = e(nl, self.h)        # H' = dropout(relu(A P1))
         self.p2 = e(nl, self.c)
         self.z = e(nl, self.c)
         self.dz = e(nl, self.c)
@@ -93,13 +93,14 @@ class FullBatchGCN(object):
             self.slab = None
 
     # ------------------------------------------------------------ collectives
-    def _aggregate(self, which, src, dst, relu):
+    def _aggregate(self, which, src, dst, relu, dropout=None):
         """dst = act(A @ [src; halo rows of src]) for A = A_hat (which='fwd') or
         A_hat^T ('bwd'); src, dst are [n_loc, W].  With several ranks the halo
         rows are fetched in column slabs: the exchange of slab s+1 is in flight
         on the communication stream while the SpMM of slab s runs."""
         if self.world == 1:
-            self.k.spmm(self.a if which == "fwd" else self.at, src, out=dst, relu=relu)
+            self.k.spmm(self.a if which == "fwd" else self.at, src, out=dst, relu=relu,
+                        dropout=None if dropout is None else dropout + (dst.shape[1], 0))
             return
         plan = self.plan if which == "fwd" else self.plan_bwd
         w = src.shape[1]
@@ -124,7 +125,8 @@ class FullBatchGCN(object):
             if work is not None:
                 work.wait()
             self.k.spmm(plan.csr, src[:, c0:c0 + nc], out=dst[:, c0:c0 + nc], relu=relu,
-                        b2=hb if plan.n_halo else None)
+                        b2=hb if plan.n_halo else None,
+                        dropout=None if dropout is None else dropout + (dst.shape[1], c0))
 
     def _all_to_all_start(self, recv, send, recv_counts, send_counts):
         """Start the variable-size all-to-all (rows of dim 0); returns a work
@@ -156,13 +158,11 @@ class FullBatchGCN(object):
         else:
             xin = self.x
         k.gemm(xin, self.w1, out=self.p1)
-        self._aggregate("fwd", self.p1, self.hb, relu=True)
-        if keep < 1.0:
-            k.dropout_philox(self.hb.view(-1), keep, self.seed * 2 + 2, off + self.row_begin * self.h,
-                             out=self.hd.view(-1), mask_out=self.mask2)
-            hin = self.hd
-        else:
-            hin = self.hb
+        # H' = dropout(relu(A P1)) straight out of the SpMM epilogue; H itself is
+        # never stored (the backward pass only needs the sign pattern of H')
+        drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h) if keep < 1.0 else None
+        self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop)
+        hin = self.hd
         k.gemm(hin, self.w2, out=self.p2)
         self._aggregate("fwd", self.p2, self.z, relu=False)
         return xin, hin
@@ -183,16 +183,10 @@ class FullBatchGCN(object):
         # layer 2
         self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
-        k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1)                # dP2 W2^T -> dH'
-        if keep < 1.0:
-            off = self.step_no * (1 << 44)
-            k.relu_dropout_bwd_philox(self.hb.view(-1), self.p1.view(-1), keep, self.seed * 2 + 2,
-                                      off + self.row_begin * self.h, out=self.hd.view(-1))
-        else:
-            k.relu_dropout_bwd(self.hb.view(-1), self.p1.view(-1), None, 1.0, out=self.hd.view(-1))
-        # hd now holds d(A P1)
+        # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
+        k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
         # layer 1
-        self._aggregate("bwd", self.hd, self.hb, relu=False)             # A^T dH -> dP1
+        self._aggregate("bwd", self.p1, self.hb, relu=False)             # A^T dH -> dP1
         k.gemm(xin, self.hb, trans_a=True, out=self.g1)                     # X'^T dP1
         self._allreduce(self.g1)
         self._allreduce(self.g2)

@@ -22,13 +22,16 @@ def _check_dense(t, name):
 
 
 # ------------------------------------------------------------------------ SpMM
-def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False, b2=None):
+def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False, b2=None,
+         dropout=None):
     """``out = act(alpha * A' @ b + beta * out)`` with ``A`` a :class:`Csr`.
     ``mask`` (uint8, in the order of the tuple ``A`` was built from) applies
     sparse dropout to the values on the fly.  Replaces ``dot(x, y, sparse=True)``
     (reference gcn/layers.py:30-33) and ``sparse_dropout`` (:21-27).
     With ``b2`` the dense operand is the row-wise concatenation ``[b; b2]``
-    without being assembled (local rows + halo rows of a partitioned run)."""
+    without being assembled (local rows + halo rows of a partitioned run).
+    ``dropout=(keep, seed, offset, ld, col0)`` applies dropout to the output in
+    the epilogue (element (r, c) has Philox index offset + r*ld + col0 + c)."""
     lib = _lib.load()
     _check_dense(b, "b")
     rows_b2 = 0
@@ -55,6 +58,11 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
         if mask.dtype != torch.uint8 or mask.numel() != a.nnz or mask.device != a.device:
             raise ValueError("mask must be uint8 with one byte per nonzero on A's device")
         midx = a.input_index
+    drop = None
+    if dropout is not None and dropout[0] < 1.0:
+        keep, seed, offset, ld, col0 = dropout
+        drop = C.byref(_lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld),
+                                          int(col0)))
     with torch.cuda.device(a.device):
         need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
         ws = WORKSPACE.get(need, a.device)
@@ -62,7 +70,7 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
             a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
             _ptr(b2 if rows_b2 else None), b2.stride(0) if rows_b2 else 0, b.shape[0],
             _ptr(out), out.stride(0), width, float(alpha), float(beta), _ptr(mask), _ptr(midx),
-            float(mask_scale), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+            float(mask_scale), 1 if relu else 0, drop, _ptr(ws), ws.numel(), _stream()))
     return out
 
 
@@ -97,9 +105,12 @@ def spmm_autograd(a, b, mask=None, mask_scale=1.0, relu=False):
 
 
 # ------------------------------------------------------------------------ GEMM
-def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False):
+def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
+         gate_scale=1.0):
     """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
-    ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35)."""
+    ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35).  With ``gate``
+    (same shape as out) the epilogue is ``gate > 0 ? out * gate_scale : 0``: the
+    backward of relu + dropout fused into the product that feeds it."""
     lib = _lib.load()
     _check_dense(a, "a")
     _check_dense(b, "b")
@@ -118,9 +129,19 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     with torch.cuda.device(a.device):
         need = lib.gcnx_gemm_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         ws = WORKSPACE.get(need, a.device)
-        _lib.check(lib.gcnx_gemm_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
-                                     _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
-                                     float(beta), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+        if gate is not None:
+            _check_dense(gate, "gate")
+            if tuple(gate.shape) != (M, N) or relu:
+                raise ValueError("gate must have the shape of out and excludes relu")
+            _lib.check(lib.gcnx_gemm_gated_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
+                                               a.stride(0), _ptr(b), b.stride(0), _ptr(out),
+                                               out.stride(0), float(alpha), float(beta), _ptr(gate),
+                                               gate.stride(0), float(gate_scale), _ptr(ws),
+                                               ws.numel(), _stream()))
+        else:
+            _lib.check(lib.gcnx_gemm_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                         _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
+                                         float(beta), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
     return out
 
 

@@ -56,6 +56,19 @@ typedef struct gcnx_csr {
   const float *val;       /* [nnz] */
 } gcnx_csr;
 
+/* Dropout fused into the epilogue of a product (replaces tf.nn.dropout on the
+ * product's output, gcn/layers.py:210): output element (r, c) is kept iff the
+ * Philox uniform of (seed, offset + r * ld + col0 + c) is < keep (the rule of
+ * gcnx_bernoulli_mask_u8), survivors are scaled by 1/keep.  ld / col0 locate a
+ * column slab inside the full activation. */
+typedef struct gcnx_dropout {
+  float keep;
+  uint64_t seed;
+  uint64_t offset;
+  int64_t ld;
+  int64_t col0;
+} gcnx_dropout;
+
 int gcnx_abi_version(void);
 const char *gcnx_last_error(void);
 /* Number of nonzeros one wavefront owns in the SpMM kernels (the unit of the
@@ -127,8 +140,9 @@ int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row,
                             int64_t ldb2, int64_t split_col, float *C,
                             int64_t ldc, int32_t width, float alpha, float beta,
                             const uint8_t *val_mask, const int64_t *mask_index,
-                            float mask_scale, int fuse_relu, void *ws,
-                            size_t ws_bytes, void *stream);
+                            float mask_scale, int fuse_relu,
+                            const gcnx_dropout *out_dropout /* nullable */,
+                            void *ws, size_t ws_bytes, void *stream);
 
 /* ---- halo exchange of a row-partitioned graph (no counterpart in the
  * reference, which is single-process) ---------------------------------------
@@ -186,6 +200,17 @@ int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                   const float *A, int64_t lda, const float *B, int64_t ldb,
                   float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
                   void *ws, size_t ws_bytes, void *stream);
+
+/* The same product with a gate in the epilogue: C = gate > 0 ? C * gate_scale : 0
+ * element-wise, gate an M x N matrix.  With gate = dropout(relu(.)) of the
+ * forward pass and gate_scale = 1/keep this is the backward of relu followed by
+ * dropout (gcn/layers.py:226,210) applied to dP * W^T without a separate pass:
+ * dropout(relu(h)) > 0 exactly where h > 0 and the element was kept. */
+int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                        const float *A, int64_t lda, const float *B, int64_t ldb,
+                        float *C, int64_t ldc, float alpha, float beta,
+                        const float *gate, int64_t ldgate, float gate_scale,
+                        void *ws, size_t ws_bytes, void *stream);
 
 /* ---- glue kernels of one training step ------------------------------------ */
 

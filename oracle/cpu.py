@@ -250,6 +250,15 @@ def bernoulli_mask(n, keep, seed, offset=0):
     return (u < np.float32(keep)).astype(np.uint8)
 
 
+def bernoulli_mask_at(index, keep, seed):
+    """Mask bits at arbitrary global element indices (uint64 array)."""
+    e = np.asarray(index, dtype=np.uint64).ravel()
+    r = philox4x32_10(e >> np.uint64(2), np.uint64(0), seed)
+    w = r[np.arange(e.size), (e & np.uint64(3)).astype(np.int64)]
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u < np.float32(keep)).astype(np.uint8).reshape(np.shape(index))
+
+
 def _splitmix64(x):
     x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
     z = x

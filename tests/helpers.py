@@ -86,20 +86,29 @@ class OracleKernels(object):
         out.copy_(src[idx.long()])
         return out
 
-    def spmm(self, a, b, out=None, relu=False, b2=None, **kw):
+    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, **kw):
         if b2 is not None:
             b = self.torch.cat([b, b2], 0)
         r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
         if relu:
             r = np.maximum(r, 0)
+        if dropout is not None and dropout[0] < 1.0:
+            keep, seed, offset, ld, col0 = dropout
+            rows = np.arange(r.shape[0], dtype=np.uint64)[:, None]
+            cols = np.arange(r.shape[1], dtype=np.uint64)[None, :]
+            idx = np.uint64(offset) + rows * np.uint64(ld) + np.uint64(col0) + cols
+            m = self.o.bernoulli_mask_at(idx, keep, seed)
+            r = np.where(m != 0, r * np.float32(1.0 / keep), np.float32(0)).astype(np.float32)
         t = self.torch.from_numpy(r)
         if out is None:
             return t
         out.copy_(t)
         return out
 
-    def gemm(self, a, b, trans_a=False, trans_b=False, out=None, **kw):
+    def gemm(self, a, b, trans_a=False, trans_b=False, out=None, gate=None, gate_scale=1.0, **kw):
         r = self.torch.from_numpy(self.o.gemm(a.contiguous().numpy(), b.contiguous().numpy(), trans_a, trans_b))
+        if gate is not None:
+            r = self.torch.where(gate > 0, r * gate_scale, self.torch.zeros_like(r))
         if out is None:
             return r
         out.copy_(r)

@@ -352,3 +352,32 @@ def test_halo_plan_and_gather_rows(env):
     sub = torch.empty((len(need_ref), 7), device=env["dev"])
     env["ops"].gather_rows(b[:, 3:10], need, sub)
     assert torch.equal(sub, b[need.long(), 3:10])
+
+
+@pytest.mark.parametrize("width,ld,col0", [(256, 256, 0), (64, 256, 128), (16, 16, 0), (7, 21, 7)])
+def test_spmm_output_dropout_epilogue(env, width, ld, col0):
+    """relu + dropout fused behind the product equals the product followed by
+    the stand-alone mask (same Philox indices)."""
+    torch = env["torch"]
+    a, b, rp, ci, v, _, _ = _spmm_case(env, 2000, 1500, 40000, width, hub=[(3, 3000)], seed=33)
+    bt = torch.from_numpy(b).to(env["dev"])
+    off = 7 * (1 << 44) + 4 * 12345
+    plain = env["ops"].spmm(a, bt, relu=True).cpu().numpy()
+    got = env["ops"].spmm(a, bt, relu=True, dropout=(0.5, 991, off, ld, col0)).cpu().numpy()
+    rows = np.arange(2000, dtype=np.uint64)[:, None]
+    cols = np.arange(width, dtype=np.uint64)[None, :]
+    m = env["oracle"].bernoulli_mask_at(np.uint64(off) + rows * np.uint64(ld) + np.uint64(col0) + cols, 0.5, 991)
+    assert np.array_equal(got, np.where(m != 0, plain * np.float32(2.0), np.float32(0)))
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 0, 700, 33, 20), (1, 0, 256, 16, 30000)])
+def test_gemm_gated_epilogue(env, ta, tb, M, N, K):
+    torch = env["torch"]
+    rng = np.random.RandomState(M + K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    gate = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)
+    at, bt, gt = (torch.from_numpy(t).to(env["dev"]) for t in (a, b, gate))
+    plain = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
+    got = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb), gate=gt, gate_scale=2.0).cpu().numpy()
+    assert np.array_equal(got, np.where(gate > 0, plain * np.float32(2.0), np.float32(0)))
