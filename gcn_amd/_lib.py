@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgcnhip.so")
+# GCNX_LIB overrides the path (kernel-variant experiments during development)
+LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
 OK = 0
 ERR_INVALID_ARG = -1

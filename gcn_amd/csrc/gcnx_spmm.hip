@@ -113,8 +113,15 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &a, int64_t r, int
   vstore<VEC>(dst, out);
 }
 
+#ifndef GCNX_WIDE_U
+#define GCNX_WIDE_U 8       // gathers in flight per wavefront in the wide kernel
+#endif
+#ifndef GCNX_WIDE_WAVES
+#define GCNX_WIDE_WAVES 4   // wavefronts per SIMD the wide kernel is register-budgeted for
+#endif
+
 template <int VEC, int U>
-__global__ __launch_bounds__(kBlock) void spmm_chunk_kernel(const SpmmArgs a) {
+__global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(const SpmmArgs a) {
   typedef typename vec_of<VEC>::type V;
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -551,8 +558,8 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
 #define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, 4>), dim3(gx), dim3(kBlock), 0, st, k)
   if (lanes > 32) {
     gy = (unsigned)ceil_div(lanes, kWave);
-    if (v4) hipLaunchKernelGGL((spmm_chunk_kernel<4, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
-    else hipLaunchKernelGGL((spmm_chunk_kernel<1, 8>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    if (v4) hipLaunchKernelGGL((spmm_chunk_kernel<4, GCNX_WIDE_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    else hipLaunchKernelGGL((spmm_chunk_kernel<1, GCNX_WIDE_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
   } else if (v4) {
     if (lanes > 16) GCNX_SLOT(4, 32);
     else if (lanes > 8) GCNX_SLOT(4, 16);

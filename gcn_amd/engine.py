@@ -71,10 +71,9 @@ class FullBatchGCN(object):
         self.dz = e(nl, self.c)
         self.dp2 = e(nl, self.c)
         self.g1, self.g2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
-        # dropout masks are regenerated from Philox where they are needed; they
-        # are only stored when a caller asks for them (keep_masks, for tests)
+        # dropout masks never touch memory (they are Philox functions of the
+        # element index); the input mask is stored only on request (keep_masks)
         self.mask1 = e(nl * self.f, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
-        self.mask2 = e(nl * self.h, dtype=torch.uint8) if (self.keep < 1.0 and keep_masks) else None
         # halo exchange (only with more than one rank)
         self.plan = self.plan_bwd = None
         if self.world > 1:
