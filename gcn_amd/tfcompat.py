@@ -464,6 +464,15 @@ class _Run(object):
         return ops.bernoulli_mask(n, keep, key, self.sess.run_counter * (2 ** 40), device())
 
     def value(self, node):
+        if isinstance(node, np.ndarray) and node.ndim >= 1:
+            # a numpy array used where a tensor is expected (e.g. the output of
+            # one sess.run passed into the next graph piece) becomes a constant
+            key = id(node)
+            hit = self.sess._cache.get(key)
+            if hit is None or hit[0] is not node:
+                hit = (node, torch.from_numpy(np.ascontiguousarray(node, dtype=np.float32)).to(device()))
+                self.sess._cache[key] = hit
+            return hit[1]
         if not isinstance(node, Node):
             return node
         if node in self.memo:

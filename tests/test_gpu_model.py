@@ -192,3 +192,22 @@ def test_save_and_load_roundtrip(tmp_path, monkeypatch):
     m.load(sess)
     for k, v in m.vars.items():
         assert np.array_equal(v.numpy(), before[k])
+
+
+def test_phase_trainer_and_analytic_counts():
+    """The per-phase loop (the fork's update / aggregate split) runs, its four
+    stages compose to A.relu(relu-free?) as defined by the fork, and the
+    analytic counts equal the fork's formulas at Cora's sizes."""
+    import oracle
+    from gcn_amd import tfcompat as tf, train_phases, utils
+    F = _setup("gcn", "cora", 2)
+    out = train_phases.run(verbose=False)
+    st = out["dataset_stats"]
+    assert (st["num_nodes"], st["feature_dim"], st["output_dim"], st["adj_nnz"]) == (2708, 1433, 7, 10556)
+    tfc = out["total_flops"]
+    assert tfc == {"layer1_update": 2708 * 1433 * 16, "layer1_aggregate": 10556 * 1433,
+                   "layer2_update": 2708 * 16 * 7, "layer2_aggregate": 10556 * 16}
+    assert abs(out["total_amir"] - (10556 * 1433 + 10556 * 16) / (2708 * 1433 * 16 + 2708 * 16 * 7)) < 1e-12
+    assert len(out["epochs"]) == 2 and all(out["phase_ms_median"][p] > 0 for p in train_phases.PHASES)
+    assert out["last_stage_output"].shape == (2708, 7)
+    assert np.isfinite(out["epochs"][-1]["train_loss"])
