@@ -99,12 +99,14 @@ def test_engine_steps_match_oracle(env, hidden, classes):
     assert abs(ev[0] - xent) <= 1e-5 * abs(xent) + 1e-6
 
 
-def test_spmm_properties_at_scale(env):
-    """RMAT scale 20 (17 M nonzeros, hub rows of ~40 k) at F=256: sampled rows
-    against an fp64 gather on the device, row sums (A_hat . 1), linearity and
-    run-to-run bitwise reproducibility."""
+@pytest.mark.parametrize("scale", [20, 24])
+def test_spmm_properties_at_scale(env, scale):
+    """RMAT scale 20 and the headline scale 24 (280 M nonzeros, hub rows of
+    240 k) at F=256: sampled rows against an fp64 gather on the device, row sums
+    (A_hat . 1), linearity and run-to-run bitwise reproducibility."""
     torch, dev = env["torch"], env["dev"]
-    a = env["rmat"].rmat_ahat(20, 8, 123, dev)
+    torch.cuda.empty_cache()
+    a = env["rmat"].rmat_ahat(scale, 8, 123, dev)
     n = a.n_rows
     g = torch.Generator(device=dev)
     g.manual_seed(1)
@@ -136,6 +138,7 @@ def test_spmm_properties_at_scale(env):
     lhs = env["ops"].spmm(a, 2 * b + c)
     rhs = 2 * out + env["ops"].spmm(a, c)
     assert float((lhs - rhs).abs().max()) <= 1e-4
+    del lhs, rhs, c, out2
     # transpose of a symmetric matrix reproduces it bit for bit
     t = a.transpose()
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)

@@ -381,3 +381,36 @@ def test_gemm_gated_epilogue(env, ta, tb, M, N, K):
     plain = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
     got = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb), gate=gt, gate_scale=2.0).cpu().numpy()
     assert np.array_equal(got, np.where(gate > 0, plain * np.float32(2.0), np.float32(0)))
+
+
+def test_cabi_error_codes_not_exceptions(env):
+    """Bad arguments come back as negative status codes with a message; nothing
+    aborts or throws through the C boundary."""
+    import ctypes as C
+    from gcn_amd import _lib
+    torch = env["torch"]
+    lib = _lib.load()
+    a = env["sparse"].Csr.from_coo([0, 1], [1, 0], [1.0, 2.0], (2, 2), env["dev"])
+    b = torch.ones((2, 4), device=env["dev"])
+    out = torch.empty((2, 4), device=env["dev"])
+    P = lambda t: C.c_void_p(t.data_ptr())
+    # workspace too small
+    rc = lib.gcnx_spmm_csr_f32(a.struct_ref(), P(a.chunk_row), P(b), 4, P(out), 4, 4, 1.0, 0.0, None, None,
+                               1.0, 0, None, 0, None)
+    assert rc == _lib.ERR_WORKSPACE and b"workspace" in lib.gcnx_last_error()
+    # leading dimension smaller than the width
+    ws = torch.empty(4096, dtype=torch.uint8, device=env["dev"])
+    rc = lib.gcnx_spmm_csr_f32(a.struct_ref(), P(a.chunk_row), P(b), 2, P(out), 4, 4, 1.0, 0.0, None, None,
+                               1.0, 0, P(ws), 4096, None)
+    assert rc == _lib.ERR_INVALID_ARG
+    rc = lib.gcnx_gemm_f32(0, 0, 2, 2, -1, P(b), 4, P(b), 4, P(out), 4, 1.0, 0.0, 0, None, 0, None)
+    assert rc == _lib.ERR_INVALID_ARG
+    rc = lib.gcnx_adam_step_f32(4, P(out), P(out), P(out), P(out), 0.01, 0.9, 0.999, 1e-8, 0.0, 0, None)
+    assert rc == _lib.ERR_INVALID_ARG          # t counts from 1
+    cnt = C.c_int64(0)
+    rc = lib.gcnx_rmat_edges(40, 0, 10, 0.57, 0.19, 0.19, 1, 0, 10, None, 0, C.byref(cnt), P(ws), None)
+    assert rc == _lib.ERR_INVALID_ARG and b"scale" in lib.gcnx_last_error()
+    with pytest.raises(ValueError):
+        env["ops"].spmm(a, torch.ones((3, 4), device=env["dev"]))
+    with pytest.raises(RuntimeError):
+        env["ops"].spmm(a, torch.ones((2, 4)))          # CPU tensor: no fallback

@@ -196,7 +196,7 @@ def test_save_and_load_roundtrip(tmp_path, monkeypatch):
 
 def test_phase_trainer_and_analytic_counts():
     """The per-phase loop (the fork's update / aggregate split) runs, its four
-    stages compose to A.relu(relu-free?) as defined by the fork, and the
+    stages produce the [N, classes] output of the split path, and the
     analytic counts equal the fork's formulas at Cora's sizes."""
     import oracle
     from gcn_amd import tfcompat as tf, train_phases, utils
