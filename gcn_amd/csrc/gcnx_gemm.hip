@@ -12,6 +12,7 @@
 // split writes its tile to the workspace and gemm_reduce_kernel adds the tiles
 // in split order, so the sum is reproducible.
 #include "gcnx_common.h"
+#include "gcnx_philox.h"
 
 namespace gcnx {
 
@@ -33,7 +34,26 @@ struct GemmArgs {
   const float *gate;   // nullable: out = gate > 0 ? out * gate_scale : 0
   int64_t ldgate;
   float gate_scale;
+  // dropout applied to A while it is staged (keep >= 1: off); element (r, c) of
+  // A as stored has Philox index adrop_offset + r * adrop_ld + c
+  float adrop_keep;
+  uint64_t adrop_seed;
+  uint64_t adrop_offset;
+  int64_t adrop_ld;
 };
+
+typedef float __attribute__((ext_vector_type(4))) f4v;
+
+// four consecutive elements starting at stored position (r, c), c % 4 == 0
+__device__ __forceinline__ f4v drop4(const GemmArgs &g, f4v v, int64_t r, int64_t c) {
+  const uint64_t e0 = g.adrop_offset + (uint64_t)r * (uint64_t)g.adrop_ld + (uint64_t)c;
+  const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, g.adrop_seed);
+  const float inv = 1.0f / g.adrop_keep;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    v[i] = ((float)(rnd.v[i] >> 8) * (1.0f / 16777216.0f) < g.adrop_keep) ? v[i] * inv : 0.0f;
+  return v;
+}
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs &g, float acc, float *dst, int64_t gm,
                                                int64_t gn) {
@@ -132,7 +152,6 @@ __global__ __launch_bounds__(kBlock) void gemm_reduce_kernel(const GemmArgs g) {
 // A[i=lane&31][k=lane>>5] and B[k=lane>>5][j=lane&31] as one float each.
 // ---------------------------------------------------------------------------
 typedef float __attribute__((ext_vector_type(16))) f16v;
-typedef float __attribute__((ext_vector_type(4))) f4v;
 
 constexpr int MB = 128, KB = 16;
 
@@ -169,7 +188,10 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
       const int m = e >> 2, q = e & 3;
       const int64_t gm = m0 + m;
       f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (gm < g.M) v = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
+      if (gm < g.M) {
+        v = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
+        if (g.adrop_keep < 1.0f) v = drop4(g, v, gm, kk + q * 4);
+      }
       float *d = As + m * (KB + 1) + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -275,7 +297,10 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
       f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (kk + k < kend) v = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      if (kk + k < kend) {
+        v = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+        if (g.adrop_keep < 1.0f) v = drop4(g, v, kk + k, m0 + q * 4);
+      }
       *reinterpret_cast<f4v *>(As + k * BM + q * 4) = v;
     }
     if constexpr (BN == 128) {
@@ -376,14 +401,35 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
-                     void *ws, size_t ws_bytes, void *stream);
+                     const gcnx_dropout *a_drop, void *ws, size_t ws_bytes, void *stream);
 
 extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                              const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                              int64_t ldc, float alpha, float beta, int fuse_relu, void *ws,
                              size_t ws_bytes, void *stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr,
-                   0, 1.0f, ws, ws_bytes, stream);
+                   0, 1.0f, nullptr, ws, ws_bytes, stream);
+}
+
+// Shape part of the MFMA dispatch rules (pointer alignment is checked at call time).
+static bool nn_mfma_shape(int64_t M, int64_t N, int64_t K) {
+  return M >= 4 * 128 && (K % 16 == 0) && (N >= 64 || K >= 64) && (N % 128 == 0 || N <= 32);
+}
+
+extern "C" int gcnx_gemm_dropout_a_supported(int trans_a, int trans_b, int64_t M, int64_t N,
+                                             int64_t K) {
+  if (trans_a) return (!trans_b && tn_mfma_shape(M, N, K) && M % 4 == 0) ? 1 : 0;
+  return (nn_mfma_shape(M, N, K) && K % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int gcnx_gemm_dropout_a_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                       const float *A, int64_t lda, const gcnx_dropout *a_dropout,
+                                       const float *B, int64_t ldb, float *C, int64_t ldc,
+                                       float alpha, float beta, void *ws, size_t ws_bytes,
+                                       void *stream) {
+  GCNX_REQUIRE(a_dropout, GCNX_ERR_INVALID_ARG, "gemm_dropout_a: null descriptor");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f,
+                   a_dropout, ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
@@ -393,13 +439,13 @@ extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t 
                                    size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(gate && ldgate >= N, GCNX_ERR_INVALID_ARG, "gemm_gated: bad gate");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, gate, ldgate,
-                   gate_scale, ws, ws_bytes, stream);
+                   gate_scale, nullptr, ws, ws_bytes, stream);
 }
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
-                     void *ws, size_t ws_bytes, void *stream) {
+                     const gcnx_dropout *a_drop, void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
   if (M == 0 || N == 0) return GCNX_OK;
   GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
@@ -413,11 +459,19 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   g.alpha = alpha; g.beta = beta; g.relu = fuse_relu;
   g.partial = nullptr; g.splits = 1; g.k_per_split = K > 0 ? K : 1;
   g.gate = gate; g.ldgate = ldgate; g.gate_scale = gate_scale;
+  g.adrop_keep = 1.0f; g.adrop_seed = 0; g.adrop_offset = 0; g.adrop_ld = 0;
+  const bool want_adrop = a_drop && a_drop->keep < 1.0f;
+  if (want_adrop) {
+    GCNX_REQUIRE(a_drop->keep > 0.0f && a_drop->offset % 4 == 0 && a_drop->ld % 4 == 0 &&
+                     a_drop->col0 == 0,
+                 GCNX_ERR_INVALID_ARG, "gemm: A-dropout needs keep > 0, offset and ld multiples of 4, col0 = 0");
+    g.adrop_keep = a_drop->keep; g.adrop_seed = a_drop->seed; g.adrop_offset = a_drop->offset;
+    g.adrop_ld = a_drop->ld;
+  }
 
   // MFMA for tall products once a weight dimension reaches 64 (hidden >= 64);
   // narrower layers stay on the VALU kernel.
-  const bool mfma_ok = !trans_a && M >= 4 * MB && (K % KB == 0) && (N >= 64 || K >= 64) &&
-                       (N % 128 == 0 || N <= 32) && (lda % 4 == 0) && aligned16(A) &&
+  const bool mfma_ok = !trans_a && nn_mfma_shape(M, N, K) && (lda % 4 == 0) && aligned16(A) &&
                        (trans_b || N <= 32 || ((ldb % 4 == 0) && aligned16(B)));
   if (mfma_ok) {
     // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
@@ -462,6 +516,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     return GCNX_OK;
   }
 
+  GCNX_REQUIRE(!want_adrop, GCNX_ERR_UNSUPPORTED,
+               "gemm: dropout on A is only fused into the MFMA kernels (tall A, a weight dimension >= 64)");
   const int splits = choose_splits(M, N, K);
   if (splits > 1) {
     const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);

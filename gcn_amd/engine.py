@@ -62,7 +62,12 @@ class FullBatchGCN(object):
         e = lambda *s, **kw: torch.empty(s, dtype=kw.get("dtype", torch.float32), device=self.dev)
         nl = self.n_loc
         # activations / gradients of the local rows, allocated once
-        self.xd = e(nl, self.f)        # dropout(X)
+        # dropout(X) is regenerated inside the two products that read it when
+        # their shapes are served by the MFMA kernels; otherwise it is stored
+        sup = getattr(self.k, "gemm_supports_a_dropout", None)
+        self.fuse_x_dropout = bool(self.keep < 1.0 and not keep_masks and sup is not None and
+                                   sup(False, nl, self.h, self.f) and sup(True, self.f, self.h, nl))
+        self.xd = None if (self.fuse_x_dropout or self.keep >= 1.0) else e(nl, self.f)   # dropout(X)
         self.p1 = e(nl, self.h)        # X' W1; later the gradient wrt A P1
         self.hb = e(nl, self.h)        # A^T dH (gradient wrt P1)
         self.hd = e(nl, self.h)        # H' = dropout(relu(A P1))
@@ -149,14 +154,22 @@ class FullBatchGCN(object):
     def forward(self, train):
         k = self.k
         keep = self.keep if train else 1.0
+        xdrop = None
         if keep < 1.0:
             off = self.step_no * (1 << 44)
-            k.dropout_philox(self.x.view(-1), keep, self.seed * 2 + 1, off + self.row_begin * self.f,
-                             out=self.xd.view(-1), mask_out=self.mask1)
-            xin = self.xd
+            xkey = (keep, self.seed * 2 + 1, off + self.row_begin * self.f)
+            if self.fuse_x_dropout:
+                xin, xdrop = self.x, xkey
+            else:
+                k.dropout_philox(self.x.view(-1), xkey[0], xkey[1], xkey[2], out=self.xd.view(-1),
+                                 mask_out=self.mask1)
+                xin = self.xd
         else:
             xin = self.x
-        k.gemm(xin, self.w1, out=self.p1)
+        if xdrop is not None:
+            k.gemm(xin, self.w1, out=self.p1, a_dropout=xdrop)
+        else:
+            k.gemm(xin, self.w1, out=self.p1)
         # H' = dropout(relu(A P1)) straight out of the SpMM epilogue; H itself is
         # never stored (the backward pass only needs the sign pattern of H')
         drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h) if keep < 1.0 else None
@@ -164,7 +177,7 @@ class FullBatchGCN(object):
         hin = self.hd
         k.gemm(hin, self.w2, out=self.p2)
         self._aggregate("fwd", self.p2, self.z, relu=False)
-        return xin, hin
+        return xin, hin, xdrop
 
     def loss(self, want_grad):
         out, _ = self.k.masked_softmax_xent(self.z, self.y, self.ymask, want_grad=want_grad,
@@ -176,7 +189,7 @@ class FullBatchGCN(object):
         [cross-entropy part of the loss, accuracy] (before the update)."""
         k = self.k
         self.step_no += 1
-        xin, hin = self.forward(train=True)
+        xin, hin, xdrop = self.forward(train=True)
         out = self.loss(want_grad=True)
         keep = self.keep
         # layer 2
@@ -186,7 +199,10 @@ class FullBatchGCN(object):
         k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
         # layer 1
         self._aggregate("bwd", self.p1, self.hb, relu=False)             # A^T dH -> dP1
-        k.gemm(xin, self.hb, trans_a=True, out=self.g1)                     # X'^T dP1
+        if xdrop is not None:
+            k.gemm(xin, self.hb, trans_a=True, out=self.g1, a_dropout=xdrop)  # X'^T dP1, X' regenerated
+        else:
+            k.gemm(xin, self.hb, trans_a=True, out=self.g1)                 # X'^T dP1
         self._allreduce(self.g1)
         self._allreduce(self.g2)
         k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)

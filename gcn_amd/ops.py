@@ -106,11 +106,14 @@ def spmm_autograd(a, b, mask=None, mask_scale=1.0, relu=False):
 
 # ------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
-         gate_scale=1.0):
+         gate_scale=1.0, a_dropout=None):
     """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
     ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35).  With ``gate``
     (same shape as out) the epilogue is ``gate > 0 ? out * gate_scale : 0``: the
-    backward of relu + dropout fused into the product that feeds it."""
+    backward of relu + dropout fused into the product that feeds it.
+    ``a_dropout=(keep, seed, offset)`` applies dropout to ``a`` (as stored,
+    row-major with its own row length) while it is read, so dropout(a) is never
+    written (MFMA shapes only)."""
     lib = _lib.load()
     _check_dense(a, "a")
     _check_dense(b, "b")
@@ -129,7 +132,16 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     with torch.cuda.device(a.device):
         need = lib.gcnx_gemm_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         ws = WORKSPACE.get(need, a.device)
-        if gate is not None:
+        if a_dropout is not None and a_dropout[0] < 1.0:
+            if gate is not None or relu or not a.is_contiguous():
+                raise ValueError("a_dropout excludes gate / relu and needs a contiguous a")
+            keep, seed, offset = a_dropout
+            d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), a.shape[1], 0)
+            _lib.check(lib.gcnx_gemm_dropout_a_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
+                                                   a.stride(0), C.byref(d), _ptr(b), b.stride(0),
+                                                   _ptr(out), out.stride(0), float(alpha), float(beta),
+                                                   _ptr(ws), ws.numel(), _stream()))
+        elif gate is not None:
             _check_dense(gate, "gate")
             if tuple(gate.shape) != (M, N) or relu:
                 raise ValueError("gate must have the shape of out and excludes relu")
@@ -143,6 +155,11 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
                                          _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
                                          float(beta), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def gemm_supports_a_dropout(trans_a, M, N, K):
+    """Whether ``gemm(..., a_dropout=...)`` is served for this shape."""
+    return bool(_lib.load().gcnx_gemm_dropout_a_supported(int(trans_a), 0, int(M), int(N), int(K)))
 
 
 class _GemmFn(torch.autograd.Function):
@@ -371,6 +388,6 @@ def profile_spmm_events(start, stop):
     lib.gcnx_profile_spmm_events(a, b)
 
 
-__all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_autograd", "masked_softmax_xent",
+__all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_supports_a_dropout", "gemm_autograd", "masked_softmax_xent",
            "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
            "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "philox_uniform", "gather_rows", "adam_step"]

@@ -201,6 +201,21 @@ int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                   float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
                   void *ws, size_t ws_bytes, void *stream);
 
+/* The same product with dropout applied to A while its tiles are staged, so
+ * dropout(A) is never written: replaces tf.nn.dropout(x) followed by
+ * tf.matmul(x', W) (gcn/layers.py:210,215) and, with trans_a, the weight
+ * gradient x'^T * dP (gcn/models.py:58) on the same regenerated mask.  The
+ * descriptor indexes A AS STORED: element (r, c) has Philox index
+ * offset + r * ld + c (col0 must be 0).  Only the MFMA kernels implement it
+ * (tall A, one weight dimension >= 64); otherwise GCNX_ERR_UNSUPPORTED. */
+int gcnx_gemm_dropout_a_supported(int trans_a, int trans_b, int64_t M, int64_t N,
+                                  int64_t K); /* 1 if the shape is served */
+int gcnx_gemm_dropout_a_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                            const float *A, int64_t lda,
+                            const gcnx_dropout *a_dropout, const float *B,
+                            int64_t ldb, float *C, int64_t ldc, float alpha,
+                            float beta, void *ws, size_t ws_bytes, void *stream);
+
 /* The same product with a gate in the epilogue: C = gate > 0 ? C * gate_scale : 0
  * element-wise, gate an M x N matrix.  With gate = dropout(relu(.)) of the
  * forward pass and gate_scale = 1/keep this is the backward of relu followed by

@@ -414,3 +414,20 @@ def test_cabi_error_codes_not_exceptions(env):
         env["ops"].spmm(a, torch.ones((3, 4), device=env["dev"]))
     with pytest.raises(RuntimeError):
         env["ops"].spmm(a, torch.ones((2, 4)))          # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("ta,M,N,K", [(0, 4096, 256, 256), (0, 3000, 16, 128), (1, 256, 256, 20000), (1, 128, 16, 9000)])
+def test_gemm_dropout_on_a_matches_materialised(env, ta, M, N, K):
+    """dropout(A) regenerated inside the product == product of the stored dropout(A)."""
+    torch = env["torch"]
+    rng = np.random.RandomState(M + K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    at, bt = torch.from_numpy(a).to(env["dev"]), torch.from_numpy(b).to(env["dev"])
+    assert env["ops"].gemm_supports_a_dropout(bool(ta), M, N, K)
+    off = 3 * (1 << 44) + 4 * 999
+    ad = env["ops"].dropout_philox(at.view(-1), 0.5, 77, off).view(at.shape)
+    ref = env["ops"].gemm(ad, bt, trans_a=bool(ta))
+    got = env["ops"].gemm(at, bt, trans_a=bool(ta), a_dropout=(0.5, 77, off))
+    assert torch.equal(ref, got)
+    assert not env["ops"].gemm_supports_a_dropout(False, 2708, 7, 16)
