@@ -357,6 +357,78 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
       }
 }
 
+// ---------------------------------------------------------------------------
+// Streaming kernel for a tiny inner dimension (K <= 32) and a wide output:
+// C[M,N] = A[M,K] * op(B), e.g. dP2 * W2^T with K = the class count.  The product
+// is bound by writing C (and reading the gate): lane l keeps its 4 output
+// columns' slice of op(B) (4 x K values) in registers, one wavefront produces one
+// full row of a 256-column slab per step with 16-byte loads / stores (1 KiB
+// coalesced per instruction), and the K values of the A row are wave-uniform
+// (scalar loads).  Four rows are in flight per wavefront.
+// ---------------------------------------------------------------------------
+template <int KMAX, bool TB>
+__global__ __launch_bounds__(kBlock) void gemm_small_k_kernel(const GemmArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t col0 = (int64_t)blockIdx.y * 256 + lane * 4;
+  const bool active = col0 < g.N;   // N % 4 == 0
+  float bw[KMAX][4];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.0f;
+      if (active && k < g.K) v = TB ? g.B[(col0 + j) * g.ldb + k] : g.B[(int64_t)k * g.ldb + col0 + j];
+      bw[k][j] = v;
+    }
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  constexpr int R = kWave / KMAX;          // rows whose A values fit one value per lane
+  const int arow_l = lane / KMAX, ak_l = lane % KMAX;
+  for (int64_t r0 = wave * R; r0 < g.M; r0 += nwaves * R) {
+    // one coalesced load brings the K values of R rows, one per lane; they are
+    // broadcast below with v_readlane (scalar operands of the FMAs)
+    float aval = 0.0f;
+    if (r0 + arow_l < g.M && ak_l < g.K) aval = g.A[(r0 + arow_l) * g.lda + ak_l];
+    f4v acc[R], gt[R], old[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      acc[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      gt[i] = f4v{1.0f, 1.0f, 1.0f, 1.0f};
+      old[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (r < g.M && active) {
+        if (g.gate) gt[i] = *reinterpret_cast<const f4v *>(g.gate + r * g.ldgate + col0);
+        if (g.beta != 0.0f) old[i] = *reinterpret_cast<const f4v *>(g.C + r * g.ldc + col0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(aval), i * KMAX + k));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a, bw[k][j], acc[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r < g.M && active) {
+        f4v out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float o = g.alpha * acc[i][j] + g.beta * old[i][j];
+          if (g.relu) o = fmaxf(o, 0.0f);
+          if (g.gate) o = gt[i][j] > 0.0f ? o * g.gate_scale : 0.0f;
+          out[j] = o;
+        }
+        *reinterpret_cast<f4v *>(g.C + r * g.ldc + col0) = out;
+      }
+    }
+  }
+}
+
 // Shapes served by gemm_mfma_tn_kernel (transposed A, plain B).
 static bool tn_mfma_shape(int64_t M, int64_t N, int64_t K) {
   return M >= 64 && M % 128 == 0 && K >= 4096 && (N % 128 == 0 || N <= 32);
@@ -467,6 +539,25 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                  GCNX_ERR_INVALID_ARG, "gemm: A-dropout needs keep > 0, offset and ld multiples of 4, col0 = 0");
     g.adrop_keep = a_drop->keep; g.adrop_seed = a_drop->seed; g.adrop_offset = a_drop->offset;
     g.adrop_ld = a_drop->ld;
+  }
+
+  // tiny inner dimension, wide output: the streaming kernel
+  const bool small_k = !trans_a && !want_adrop && K >= 1 && K <= 32 && N >= 64 && (N % 4 == 0) &&
+                       M >= 1024 && (ldc % 4 == 0) && aligned16(C) &&
+                       (!gate || ((ldgate % 4 == 0) && aligned16(gate)));
+  if (small_k) {
+    int64_t blocks = ceil_div(ceil_div(M, 2), kWavesPerBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));
+    if (K <= 16) {
+      if (trans_b) hipLaunchKernelGGL((gemm_small_k_kernel<16, true>), grid, dim3(kBlock), 0, st, g);
+      else hipLaunchKernelGGL((gemm_small_k_kernel<16, false>), grid, dim3(kBlock), 0, st, g);
+    } else {
+      if (trans_b) hipLaunchKernelGGL((gemm_small_k_kernel<32, true>), grid, dim3(kBlock), 0, st, g);
+      else hipLaunchKernelGGL((gemm_small_k_kernel<32, false>), grid, dim3(kBlock), 0, st, g);
+    }
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
   }
 
   // MFMA for tall products once a weight dimension reaches 64 (hidden >= 64);

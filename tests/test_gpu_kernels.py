@@ -195,6 +195,7 @@ def test_spmm_reproducible_and_strided(env):
     (1, 0, 16, 7, 2708), (1, 0, 256, 16, 100000), (1, 0, 256, 256, 20000), (1, 1, 33, 21, 65),
     (1, 0, 128, 7, 5000), (1, 0, 384, 128, 9999), (1, 0, 256, 32, 4100),
     (0, 0, 5000, 16, 256), (0, 0, 5001, 7, 64), (0, 1, 5000, 256, 16), (0, 1, 777, 128, 64), (0, 1, 4096, 20, 128),
+    (0, 1, 5003, 260, 7), (0, 0, 2049, 512, 32), (0, 0, 1500, 64, 3), (0, 1, 9000, 1024, 20),
 ])
 def test_gemm_matches_oracle(env, ta, tb, M, N, K):
     torch = env["torch"]
@@ -370,7 +371,8 @@ def test_spmm_output_dropout_epilogue(env, width, ld, col0):
     assert np.array_equal(got, np.where(m != 0, plain * np.float32(2.0), np.float32(0)))
 
 
-@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 0, 700, 33, 20), (1, 0, 256, 16, 30000)])
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 0, 700, 33, 20), (1, 0, 256, 16, 30000),
+                                         (0, 1, 5001, 128, 16), (0, 0, 4096, 256, 128)])
 def test_gemm_gated_epilogue(env, ta, tb, M, N, K):
     torch = env["torch"]
     rng = np.random.RandomState(M + K)
