@@ -180,46 +180,80 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
   const int li = lane & 31, lk = lane >> 5;
-  for (int64_t kk = 0; kk < g.K; kk += KB) {
-    // A: 128 rows x 16 floats = 512 float4, two per thread
+  // Software pipeline: the global loads of K-step i+1 are issued before the
+  // MFMAs of K-step i and land in registers; they are written to LDS (A with
+  // its dropout applied) after those MFMAs have been issued.
+  constexpr int NB_S = (KB * BN) / kBlock;   // scalar B elements per thread (generic paths)
+  f4v ra[2], rb[2];
+  float rbs[NB_S];
+  auto load_tiles = [&](int64_t kk) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * kBlock;
       const int m = e >> 2, q = e & 3;
       const int64_t gm = m0 + m;
-      f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (gm < g.M) {
-        v = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
-        if (g.adrop_keep < 1.0f) v = drop4(g, v, gm, kk + q * 4);
-      }
-      float *d = As + m * (KB + 1) + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (gm < g.M) ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
     }
     if constexpr (!TB && BN == 128) {
-      // B: 16 rows x 128 floats = 512 float4, two per thread
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int e = tid + i * kBlock;
         const int k = e >> 5, q = e & 31;
-        const f4v v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
-        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = v;
+        rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
       }
     } else if constexpr (!TB) {
 #pragma unroll
-      for (int i = 0; i < (KB * BN) / kBlock; ++i) {
+      for (int i = 0; i < NB_S; ++i) {
         const int e = tid + i * kBlock;
         const int k = e / BN, n = e % BN;
-        Bs[k * BN + n] = (n0 + n < g.N) ? g.B[(kk + k) * g.ldb + n0 + n] : 0.0f;
+        rbs[i] = (n0 + n < g.N) ? g.B[(kk + k) * g.ldb + n0 + n] : 0.0f;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < (KB * BN) / kBlock; ++i) {
+      for (int i = 0; i < NB_S; ++i) {
         const int e = tid + i * kBlock;
         const int n = e / KB, k = e % KB;
-        Bs[k * BN + n] = (n0 + n < g.N) ? g.B[(n0 + n) * g.ldb + kk + k] : 0.0f;
+        rbs[i] = (n0 + n < g.N) ? g.B[(n0 + n) * g.ldb + kk + k] : 0.0f;
       }
     }
+  };
+  auto store_tiles = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int m = e >> 2, q = e & 3;
+      f4v v = ra[i];
+      if (g.adrop_keep < 1.0f && m0 + m < g.M) v = drop4(g, v, m0 + m, kk + q * 4);
+      float *d = As + m * (KB + 1) + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if constexpr (!TB && BN == 128) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e >> 5, q = e & 31;
+        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = rb[i];
+      }
+    } else if constexpr (!TB) {
+#pragma unroll
+      for (int i = 0; i < NB_S; ++i) {
+        const int e = tid + i * kBlock;
+        Bs[(e / BN) * BN + (e % BN)] = rbs[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB_S; ++i) {
+        const int e = tid + i * kBlock;
+        Bs[(e % KB) * BN + (e / KB)] = rbs[i];
+      }
+    }
+  };
+  load_tiles(0);
+  for (int64_t kk = 0; kk < g.K; kk += KB) {
+    store_tiles(kk);
     __syncthreads();
+    if (kk + KB < g.K) load_tiles(kk + KB);
 #pragma unroll
     for (int k2 = 0; k2 < KB; k2 += 2) {
       if constexpr (BN == 128) {
@@ -290,39 +324,45 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  for (int64_t kk = kbeg; kk < kend; kk += BK) {
-    // A: 16 rows x 128 floats = 512 float4, two per thread
+  // software pipeline as in gemm_mfma_kernel: next K-step's tiles travel in
+  // registers while this K-step's MFMAs run
+  f4v ra[2], rb[2];
+  float rbs[2];
+  auto load_tiles = [&](int64_t kk) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
-      f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (kk + k < kend) {
-        v = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
-        if (g.adrop_keep < 1.0f) v = drop4(g, v, kk + k, m0 + q * 4);
+      ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (kk + k < kend) ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      if constexpr (BN == 128) {
+        rb[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if (kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+      } else {
+        rbs[i] = (kk + k < kend && n0 + q < g.N) ? g.B[(kk + k) * g.ldb + n0 + q] : 0.0f;
       }
+    }
+  };
+  auto store_tiles = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      f4v v = ra[i];
+      if (g.adrop_keep < 1.0f && kk + k < kend) v = drop4(g, v, kk + k, m0 + q * 4);
       *reinterpret_cast<f4v *>(As + k * BM + q * 4) = v;
-    }
-    if constexpr (BN == 128) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + i * kBlock;
-        const int k = e >> 5, q = e & 31;
-        f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (kk + k < kend) v = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
-        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = v;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + i * kBlock;
-        const int k = e >> 5, n = e & 31;
-        float v = 0.0f;
-        if (kk + k < kend && n0 + n < g.N) v = g.B[(kk + k) * g.ldb + n0 + n];
-        Bs[k * BN + n] = v;
+      if constexpr (BN == 128) {
+        *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = rb[i];
+      } else {
+        Bs[k * BN + q] = rbs[i];
       }
     }
+  };
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int64_t kk = kbeg; kk < kend; kk += BK) {
+    store_tiles(kk);
     __syncthreads();
+    if (kk + BK < kend) load_tiles(kk + BK);
 #pragma unroll
     for (int k2 = 0; k2 < BK; k2 += 2) {
       float af[TMW], bf[TNW];
