@@ -46,6 +46,7 @@ SIGNATURES = {
     "gcnx_abi_version": (_int, []),
     "gcnx_last_error": (C.c_char_p, []),
     "gcnx_spmm_chunk_nnz": (_int, []),
+    "gcnx_spmm_row_path_limit": (_i64, [_i64]),
     "gcnx_csr_from_coo_workspace_bytes": (_sz, [_i64, _i64]),
     "gcnx_csr_from_coo": (_int, [_i64, _i64, _i64, _p, _p, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "gcnx_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -75,11 +76,14 @@ SIGNATURES = {
                                             _p, _sz, _p]),
     "gcnx_dropout_dense_f32": (_int, [_i64, _p, _p, _f32, _p, _p]),
     "gcnx_bernoulli_mask_u8": (_int, [_i64, _f32, _u64, _u64, _p, _p]),
+    "gcnx_bernoulli_mask_dev_u8": (_int, [_i64, _f32, _u64, _u64, _p, _u64, _p, _p]),
+    "gcnx_counter_add_u64": (_int, [_p, _u64, _p]),
     "gcnx_philox_uniform_f32": (_int, [_i64, _f32, _f32, _u64, _u64, _p, _p]),
     "gcnx_dropout_philox_f32": (_int, [_i64, _p, _f32, _u64, _u64, _p, _p, _p]),
     "gcnx_relu_dropout_bwd_philox_f32": (_int, [_i64, _p, _p, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),
     "gcnx_adam_step_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
+    "gcnx_adam_step_dev_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p]),
     "gcnx_normalize_csr_f64": (_int, [_csr_p, _i64, _p, _p, _i64, _p, _p, _p]),
     "gcnx_rmat_workspace_bytes": (_sz, []),
     "gcnx_rmat_edges": (_int, [_i32, _i64, _i64, _f64, _f64, _f64, _u64, _i64, _i64, _p, _i64,

@@ -487,9 +487,12 @@ static int tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
 
 static int choose_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, TM) * ceil_div(N, TN);
-  if (tiles >= 1024 || K <= 4096) return 1;
+  if (tiles >= 1024 || K <= 128) return 1;
+  // one K step of the tile kernel is a full load -> LDS -> barrier round trip
+  // (~2 us when nothing else hides it), so with few tiles even a K of a few
+  // thousand is cut down to 64 per workgroup
   int64_t s = 2048 / tiles;
-  const int64_t max_s = ceil_div(K, 2048);
+  const int64_t max_s = ceil_div(K, 64);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return (int)s;

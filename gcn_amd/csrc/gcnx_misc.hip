@@ -221,11 +221,17 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(
   }
 }
 
+// t_dev (nullable): the step count is read from the device and the bias-corrected
+// rate lr * sqrt(1 - b2^t) / (1 - b1^t) formed here (lr_t then holds plain lr).
 __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float *__restrict__ w,
                                                      const float *__restrict__ g,
                                                      float *__restrict__ m, float *__restrict__ v,
                                                      float lr_t, float b1, float b2, float eps,
-                                                     float wd) {
+                                                     float wd, const uint64_t *__restrict__ t_dev) {
+  if (t_dev) {
+    const double t = (double)*t_dev;
+    lr_t = (float)((double)lr_t * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float wi = w[i];
@@ -238,11 +244,18 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float *__restri
   }
 }
 
+__global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
+
 // byte k of the mask = 1 iff uniform(seed, offset + k) < keep; four consecutive
-// global positions share one Philox block.
+// global positions share one Philox block.  step_dev (nullable) adds
+// *step_dev * step_stride to the offset: the step counter then lives on the
+// device, so a captured HIP graph draws a fresh mask on every replay.
 __global__ __launch_bounds__(kBlock) void bernoulli_kernel(int64_t n, float keep, uint64_t seed,
                                                           uint64_t offset,
+                                                          const uint64_t *__restrict__ step_dev,
+                                                          uint64_t step_stride,
                                                           uint8_t *__restrict__ mask) {
+  if (step_dev) offset += *step_dev * step_stride;
   const uint64_t first_blk = offset >> 2;
   const uint64_t last_blk = (offset + (uint64_t)n - 1) >> 2;
   const uint64_t nblk = last_blk - first_blk + 1;
@@ -469,7 +482,27 @@ extern "C" int gcnx_adam_step_f32(int64_t n, float *w, const float *grad, float 
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) /
                       (1.0 - pow((double)beta1, (double)t));
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, as_stream(stream), n, w,
-                     grad, m, v, (float)lr_t, beta1, beta2, eps, weight_decay);
+                     grad, m, v, (float)lr_t, beta1, beta2, eps, weight_decay,
+                     (const uint64_t *)nullptr);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_adam_step_dev_f32(int64_t n, float *w, const float *grad, float *m, float *v,
+                                      float lr, float beta1, float beta2, float eps,
+                                      float weight_decay, const uint64_t *t_dev, void *stream) {
+  GCNX_REQUIRE(n >= 0 && t_dev && (n == 0 || (w && grad && m && v)), GCNX_ERR_INVALID_ARG,
+               "adam_dev: bad argument");
+  if (n == 0) return GCNX_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, as_stream(stream), n, w,
+                     grad, m, v, lr, beta1, beta2, eps, weight_decay, t_dev);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_counter_add_u64(uint64_t *counter, uint64_t inc, void *stream) {
+  GCNX_REQUIRE(counter, GCNX_ERR_INVALID_ARG, "counter_add: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream), counter, inc);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }
@@ -479,7 +512,20 @@ extern "C" int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed, uint
   GCNX_REQUIRE(n >= 0 && (n == 0 || mask), GCNX_ERR_INVALID_ARG, "bernoulli: bad argument");
   if (n == 0) return GCNX_OK;
   hipLaunchKernelGGL(bernoulli_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
-                     as_stream(stream), n, keep, seed, offset, mask);
+                     as_stream(stream), n, keep, seed, offset, (const uint64_t *)nullptr,
+                     (uint64_t)0, mask);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_bernoulli_mask_dev_u8(int64_t n, float keep, uint64_t seed, uint64_t offset,
+                                          const uint64_t *step_dev, uint64_t step_stride,
+                                          uint8_t *mask, void *stream) {
+  GCNX_REQUIRE(n >= 0 && step_dev && (n == 0 || mask), GCNX_ERR_INVALID_ARG,
+               "bernoulli_dev: bad argument");
+  if (n == 0) return GCNX_OK;
+  hipLaunchKernelGGL(bernoulli_kernel, dim3(stream_grid(n / 4 + 2)), dim3(kBlock), 0,
+                     as_stream(stream), n, keep, seed, offset, step_dev, step_stride, mask);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

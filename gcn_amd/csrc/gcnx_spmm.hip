@@ -17,6 +17,8 @@
 // (slot 0: the row began in an earlier chunk; slot 1: it begins here and runs
 // on); spmm_fixup_kernel adds them in chunk order and applies the epilogue, so
 // the result does not depend on scheduling.
+#include <atomic>
+
 #include "gcnx_common.h"
 #include "gcnx_philox.h"
 
@@ -370,6 +372,57 @@ __global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
   }
 }
 
+// Small matrices with a narrow dense operand (the Planetoid graphs: 10^4..10^6
+// nonzeros): the chunk walk above is one long dependent chain per wavefront and
+// a small matrix has too few chunks to hide it.  Here ONE wavefront owns one
+// row: the S = 64 / LW slots take the row's nonzeros S at a time, the slot sums
+// are added with shuffles, slot 0 applies the epilogue.  No partial sums, no
+// second launch; the result is a fixed function of the row (reproducible).
+template <int VEC, int LW>
+__global__ __launch_bounds__(kBlock) void spmm_row_kernel(const SpmmArgs a) {
+  typedef typename vec_of<VEC>::type V;
+  constexpr int S = kWave / LW;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  if (r >= a.n_rows) return;
+  const int slot = lane / LW;
+  const int col0 = (lane % LW) * VEC;
+  const bool active = col0 < a.width;
+  const int64_t beg = a.row_ptr[r];
+  const int64_t end = a.row_ptr[r + 1];
+  V acc0 = V(0.0f), acc1 = V(0.0f);
+  auto term = [&](int64_t g) -> V {
+    if (g >= end || !active) return V(0.0f);
+    const int cc = a.col_idx[g];
+    float v = a.val[g];
+    if (a.vmask) {
+      const int64_t mi = a.mindex ? a.mindex[g] : g;
+      v = a.vmask[mi] ? v * a.mscale : 0.0f;
+    }
+    const float *src = (cc < a.split ? a.B + (int64_t)cc * a.ldb
+                                     : a.B2 + (int64_t)(cc - a.split) * a.ldb2) + col0;
+    return vload<VEC>(src) * v;
+  };
+  for (int64_t k0 = beg; k0 < end; k0 += 2 * S) {
+    const V t0 = term(k0 + slot);
+    const V t1 = term(k0 + S + slot);
+    acc0 += t0;
+    acc1 += t1;
+  }
+  V tot = acc0 + acc1;
+#pragma unroll
+  for (int off = LW; off < kWave; off <<= 1) {
+    if constexpr (VEC == 1) {
+      tot += __shfl_xor(tot, off, kWave);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) tot[i] += __shfl_xor(tot[i], off, kWave);
+    }
+  }
+  if (active && slot == 0) epilogue_store<VEC>(a, r, col0, tot);
+}
+
 // One wavefront per chunk boundary c | c+1: if the row that owns the first
 // nonzero of chunk c+1 begins inside chunk c, this wavefront completes it.
 template <int VEC>
@@ -437,6 +490,15 @@ static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 extern "C" void gcnx_profile_spmm_events(void *start, void *stop) {
   g_prof_start = static_cast<hipEvent_t>(start);
   g_prof_stop = static_cast<hipEvent_t>(stop);
+}
+
+// Matrices with at most this many nonzeros (and a dense operand of at most 32
+// lanes) take the wavefront-per-row kernel.
+static std::atomic<int64_t> g_row_path_max_nnz{(int64_t)1 << 21};
+constexpr int64_t kRowPathMaxRows = (int64_t)1 << 20;
+
+extern "C" int64_t gcnx_spmm_row_path_limit(int64_t max_nnz) {
+  return max_nnz < 0 ? g_row_path_max_nnz.load() : g_row_path_max_nnz.exchange(max_nnz);
 }
 
 extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunk; }
@@ -555,6 +617,29 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs
   unsigned gy = 1;
   if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
+  if (lanes <= 32 && a->nnz <= g_row_path_max_nnz.load() && a->n_rows <= kRowPathMaxRows) {
+    const unsigned gr = (unsigned)ceil_div(a->n_rows, kWavesPerBlock);
+#define GCNX_ROW(V, L) hipLaunchKernelGGL((spmm_row_kernel<V, L>), dim3(gr), dim3(kBlock), 0, st, k)
+    if (v4) {
+      if (lanes > 16) GCNX_ROW(4, 32);
+      else if (lanes > 8) GCNX_ROW(4, 16);
+      else if (lanes > 4) GCNX_ROW(4, 8);
+      else if (lanes > 2) GCNX_ROW(4, 4);
+      else if (lanes > 1) GCNX_ROW(4, 2);
+      else GCNX_ROW(4, 1);
+    } else {
+      if (lanes > 16) GCNX_ROW(1, 32);
+      else if (lanes > 8) GCNX_ROW(1, 16);
+      else if (lanes > 4) GCNX_ROW(1, 8);
+      else if (lanes > 2) GCNX_ROW(1, 4);
+      else if (lanes > 1) GCNX_ROW(1, 2);
+      else GCNX_ROW(1, 1);
+    }
+#undef GCNX_ROW
+    GCNX_CHECK_LAUNCH();
+    if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+    return GCNX_OK;
+  }
 #define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, 4>), dim3(gx), dim3(kBlock), 0, st, k)
   if (lanes > 32) {
     gy = (unsigned)ceil_div(lanes, kWave);

@@ -237,9 +237,29 @@ def masked_softmax_xent_autograd(logits, labels, mask):
 
 
 # ------------------------------------------------------------------ elementwise
-def bernoulli_mask(n, keep, seed, offset, device, out=None):
+def device_counter(device, value=0):
+    """A 64-bit step counter in device memory (int64 tensor of one element),
+    advanced with :func:`counter_add` on the stream."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("device_counter needs a CUDA (ROCm) device")
+    return torch.full((1,), int(value), dtype=torch.int64, device=dev)
+
+
+def counter_add(counter, inc=1):
+    lib = _lib.load()
+    if counter.device.type != "cuda" or counter.dtype != torch.int64 or counter.numel() != 1:
+        raise ValueError("counter must be a one-element int64 CUDA tensor")
+    with torch.cuda.device(counter.device):
+        _lib.check(lib.gcnx_counter_add_u64(_ptr(counter), int(inc), _stream()))
+    return counter
+
+
+def bernoulli_mask(n, keep, seed, offset, device, out=None, step=None, step_stride=0):
     """uint8 mask, byte k = 1 with probability ``keep``, a pure function of
-    (seed, offset + k) (Philox4x32-10)."""
+    (seed, offset + k) (Philox4x32-10).  With ``step`` (a device counter) the
+    offset is advanced by ``step * step_stride`` when the kernel runs, so a launch
+    recorded in a HIP graph draws a new mask on every replay."""
     lib = _lib.load()
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -251,8 +271,15 @@ def bernoulli_mask(n, keep, seed, offset, device, out=None):
     else:
         mask = torch.empty(int(n), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.gcnx_bernoulli_mask_u8(int(n), float(keep), int(seed) & (2 ** 64 - 1),
-                                              int(offset), _ptr(mask), _stream()))
+        if step is not None:
+            if step.device.type != "cuda" or step.dtype != torch.int64 or step.numel() != 1:
+                raise ValueError("step must be a one-element int64 CUDA tensor")
+            _lib.check(lib.gcnx_bernoulli_mask_dev_u8(int(n), float(keep), int(seed) & (2 ** 64 - 1),
+                                                      int(offset), _ptr(step), int(step_stride),
+                                                      _ptr(mask), _stream()))
+        else:
+            _lib.check(lib.gcnx_bernoulli_mask_u8(int(n), float(keep), int(seed) & (2 ** 64 - 1),
+                                                  int(offset), _ptr(mask), _stream()))
     return mask
 
 
@@ -364,15 +391,23 @@ def dropout_dense_autograd(x, mask, scale):
 
 
 def adam_step(w, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
-    """In-place TF-style Adam (reference gcn/models.py:142); ``t`` counts from 1."""
+    """In-place TF-style Adam (reference gcn/models.py:142); ``t`` counts from 1
+    and is either a Python int or a device counter (read when the kernel runs)."""
     lib = _lib.load()
     for name, x in (("w", w), ("grad", grad), ("m", m), ("v", v)):
         if x.device.type != "cuda" or x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("%s must be a contiguous float32 CUDA tensor" % name)
     with torch.cuda.device(w.device):
-        _lib.check(lib.gcnx_adam_step_f32(w.numel(), _ptr(w), _ptr(grad), _ptr(m), _ptr(v),
-                                          float(lr), float(beta1), float(beta2), float(eps),
-                                          float(weight_decay), int(t), _stream()))
+        if isinstance(t, torch.Tensor):
+            if t.device.type != "cuda" or t.dtype != torch.int64 or t.numel() != 1:
+                raise ValueError("t must be an int or a one-element int64 CUDA tensor")
+            _lib.check(lib.gcnx_adam_step_dev_f32(w.numel(), _ptr(w), _ptr(grad), _ptr(m), _ptr(v),
+                                                  float(lr), float(beta1), float(beta2), float(eps),
+                                                  float(weight_decay), _ptr(t), _stream()))
+        else:
+            _lib.check(lib.gcnx_adam_step_f32(w.numel(), _ptr(w), _ptr(grad), _ptr(m), _ptr(v),
+                                              float(lr), float(beta1), float(beta2), float(eps),
+                                              float(weight_decay), int(t), _stream()))
     return w
 
 

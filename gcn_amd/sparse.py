@@ -47,6 +47,12 @@ class _Workspace(object):
             self._buf[key] = buf
         return buf
 
+    def buffers(self):
+        """The buffers currently handed out; a recorded HIP graph keeps these
+        referenced so that growing the workspace later cannot free memory the
+        graph still writes."""
+        return [b for b in self._buf.values() if b is not None]
+
 
 WORKSPACE = _Workspace()
 

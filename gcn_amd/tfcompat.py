@@ -198,6 +198,7 @@ _GLOBAL_VARIABLES = []
 _SCOPE = []
 _SEED = [None]
 _RNG_CALLS = [0]
+_VAR_EPOCH = [0]   # bumped whenever a variable gets new storage (recorded graphs go stale)
 
 
 class GraphKeys(object):
@@ -223,6 +224,7 @@ class Variable(Node):
         _GLOBAL_VARIABLES.append(self)
 
     def initialize(self):
+        _VAR_EPOCH[0] += 1
         self.tensor = torch.from_numpy(self._init_value.copy()).to(device()).requires_grad_(True)
         self.adam_m = torch.zeros_like(self.tensor, requires_grad=False)
         self.adam_v = torch.zeros_like(self.tensor, requires_grad=False)
@@ -406,19 +408,27 @@ class AdamOptimizer(object):
     def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.learning_rate = learning_rate
         self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
-        self.step = 0
+        self.step = 0          # host copy, informational
+        self._step_dev = None  # the count the kernels read (advanced on the stream)
 
     def minimize(self, loss):
         return _OptOp(self, loss)
 
     def apply(self, variables, grads):
-        self.step += 1
+        """One update of every variable.  The step count lives in device memory
+        and is advanced by a kernel, so that the launches can be recorded in a
+        HIP graph and replayed."""
+        if self._step_dev is None:
+            self._step_dev = ops.device_counter(device(), self.step)
+        if not torch.cuda.is_current_stream_capturing():
+            self.step += 1
+        ops.counter_add(self._step_dev, 1)
         for v, g in zip(variables, grads):
             if g is None:
                 continue
             with torch.no_grad():
                 ops.adam_step(v.tensor, g.contiguous(), v.adam_m, v.adam_v, self.learning_rate,
-                              self.step, self.beta1, self.beta2, self.epsilon)
+                              self._step_dev, self.beta1, self.beta2, self.epsilon)
 
 
 class _Saver(object):
@@ -461,7 +471,8 @@ class _Run(object):
             m = provider(key, n, keep)
             if m is not None:
                 return torch.as_tensor(np.ascontiguousarray(m, dtype=np.uint8)).to(device())
-        return ops.bernoulli_mask(n, keep, key, self.sess.run_counter * (2 ** 40), device())
+        return ops.bernoulli_mask(n, keep, key, 0, device(), step=self.sess._run_dev,
+                                  step_stride=2 ** 40)
 
     def value(self, node):
         if isinstance(node, np.ndarray) and node.ndim >= 1:
@@ -495,25 +506,40 @@ class _Run(object):
 
 
 class Session(object):
+    """``config={"hip_graph": True}`` (or the environment variable
+    GCN_AMD_HIP_GRAPH=1) records each distinct (fetches, feed objects) call in a
+    HIP graph on its second occurrence and replays it from then on: a Planetoid
+    step is ~60 launches of microsecond kernels, so launch latency, not the
+    kernels, sets its time.  The first occurrence runs eagerly and builds the
+    cached device state (CSR uploads, transposes, merged supports).  Replays
+    require that the same Python objects are fed (the reference's training
+    loop does: gcn/train_normal.py:89-93); the values of fed arrays are read at
+    upload time only, exactly as without graphs."""
+
     def __init__(self, config=None):
         self._cache = {}
         self.run_counter = 0
+        self._run_dev = None   # device copy of run_counter: the dropout kernels read it
         # hook: mask_provider(key, n, keep) -> uint8 array or None; lets a
         # parity run share dropout masks with the oracle
         self.mask_provider = None
+        cfg = config if isinstance(config, dict) else {}
+        self.hip_graph = bool(cfg.get("hip_graph", os.environ.get("GCN_AMD_HIP_GRAPH", "0") == "1"))
+        self._graphs = {}
+        self.graph_replays = 0
 
     def to_device(self, ph, value):
         """Upload a fed value once; later feeds of the same object reuse it."""
         if isinstance(value, (SparseValue, torch.Tensor)):
             return value
+        if not ph.sparse and isinstance(value, (tuple, list, int, float)):
+            return value  # e.g. num_features_nonzero = (nnz,), dropout = 0.5
         key = id(value)
         hit = self._cache.get(key)
         if hit is not None and hit[0] is value:
             return hit[1]
         if ph.sparse:
             out = SparseValue(Csr.from_tuple(value, device()), source=value)
-        elif isinstance(value, (tuple, list, int, float)):
-            out = value  # e.g. num_features_nonzero = (nnz,), dropout = 0.5
         else:
             arr = np.asarray(value)
             if arr.ndim == 0:
@@ -525,12 +551,12 @@ class Session(object):
         self._cache[key] = (value, out)
         return out
 
-    def run(self, fetches, feed_dict=None, options=None, run_metadata=None):
-        single = not isinstance(fetches, (list, tuple))
-        flist = [fetches] if single else list(fetches)
-        device()
-        self.run_counter += 1
-        run = _Run(self, feed_dict or {})
+    def _execute(self, flist, feed):
+        """Issue every launch of one run on the current stream (no host
+        synchronisation once the fed values are resident); returns the fetched
+        values as device tensors / Python objects."""
+        ops.counter_add(self._run_dev, 1)
+        run = _Run(self, feed)
         opt_ops = [f for f in flist if isinstance(f, _OptOp)]
         results = [None] * len(flist)
         with torch.set_grad_enabled(bool(opt_ops)):
@@ -542,6 +568,57 @@ class Session(object):
                 variables = [v for v in _GLOBAL_VARIABLES if v.tensor is not None]
                 grads = torch.autograd.grad(loss, [v.tensor for v in variables], allow_unused=True)
                 op.optimizer.apply(variables, grads)
+        return [r.detach() if isinstance(r, torch.Tensor) else r for r in results]
+
+    @staticmethod
+    def _graph_key(flist, feed):
+        sig = []
+        for ph, v in feed.items():
+            if isinstance(v, (bool, int, float, np.integer, np.floating)):
+                sig.append((id(ph), "s", float(v)))
+            elif isinstance(v, np.ndarray) and v.ndim == 0:
+                sig.append((id(ph), "s", float(v)))
+            elif isinstance(v, (tuple, list)) and len(v) <= 8 and \
+                    all(isinstance(e, (bool, int, float, np.integer, np.floating)) for e in v):
+                sig.append((id(ph), "t", tuple(float(e) for e in v)))  # e.g. num_features_nonzero
+            else:
+                sig.append((id(ph), "o", id(v)))
+        sig.sort()
+        return (tuple(id(f) for f in flist), tuple(sig), _VAR_EPOCH[0], len(_GLOBAL_VARIABLES))
+
+    def run(self, fetches, feed_dict=None, options=None, run_metadata=None):
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        device()
+        self.run_counter += 1
+        if self._run_dev is None:
+            self._run_dev = ops.device_counter(device(), self.run_counter - 1)
+        feed = feed_dict or {}
+        ent = None
+        if self.hip_graph and self.mask_provider is None:
+            key = self._graph_key(flist, feed)
+            ent = self._graphs.get(key)
+            if ent is None:
+                # first occurrence: eager (it also warms every cache the graph relies on);
+                # the fed objects are kept alive so that their ids stay unique
+                self._graphs[key] = {"refs": (list(flist), list(feed.items()))}
+            elif "graph" not in ent:
+                from .sparse import WORKSPACE
+                graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph):
+                    ent["results"] = self._execute(flist, feed)
+                ent["graph"] = graph
+                ent["workspace"] = WORKSPACE.buffers()
+        if ent is not None and "graph" in ent:
+            ent["graph"].replay()
+            self.graph_replays += 1
+            for f in flist:
+                if isinstance(f, _OptOp):
+                    f.optimizer.step += 1
+            results = ent["results"]
+        else:
+            results = self._execute(flist, feed)
         out = []
         for r in results:
             if isinstance(r, torch.Tensor):

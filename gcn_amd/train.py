@@ -34,6 +34,7 @@ def define_flags():
     flags.DEFINE_integer('max_degree', 3, 'Maximum Chebyshev polynomial degree.')
     flags.DEFINE_integer('seed', 123, 'Random seed (the reference hard-codes 123).')
     flags.DEFINE_string('report', '', 'Optional path of a JSON run report.')
+    flags.DEFINE_boolean('hip_graph', False, 'Record each distinct session.run in a HIP graph and replay it.')
 
 
 def run(data=None, verbose=True, initial_weights=None, mask_provider=None):
@@ -76,7 +77,7 @@ def run(data=None, verbose=True, initial_weights=None, mask_provider=None):
     }
 
     model = model_func(placeholders, input_dim=features[2][1], logging=True)
-    sess = tf.Session()
+    sess = tf.Session(config={"hip_graph": True} if FLAGS.hip_graph else None)
     sess.mask_provider = mask_provider
 
     def evaluate(features, support, labels, mask, placeholders):

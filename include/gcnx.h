@@ -120,8 +120,16 @@ int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream);
  * Sums are formed in fp32 in slot order inside a chunk; rows that span several
  * chunks are completed from per-chunk partial sums in chunk order, so results
  * are bitwise reproducible run to run.
+ * Matrices of at most gcnx_spmm_row_path_limit(-1) nonzeros whose dense operand
+ * fits 32 lanes (128 columns with 16-byte aligned rows, else 32) are summed one
+ * wavefront per row instead (slot-strided terms, then a shuffle tree): also a
+ * fixed function of the input.
  */
 size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width);
+/* Tuning knob (process-wide): nonzero count up to which the wavefront-per-row
+ * kernel is used; returns the previous value; a negative argument only reads.
+ * 0 sends every matrix down the chunk kernels. */
+int64_t gcnx_spmm_row_path_limit(int64_t max_nnz);
 int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       const float *B, int64_t ldb, float *C, int64_t ldc,
                       int32_t width, float alpha, float beta,
@@ -255,6 +263,19 @@ int gcnx_dropout_dense_f32(int64_t n, const float *x, const uint8_t *mask,
 int gcnx_bernoulli_mask_u8(int64_t n, float keep, uint64_t seed,
                            uint64_t offset, uint8_t *mask, void *stream);
 
+/* Same mask with the offset advanced on the device: effective offset = offset
+ * + *step_dev * step_stride, read when the kernel runs.  A launch recorded in a
+ * HIP graph therefore draws a fresh mask on every replay, as session.run does
+ * on every call of gcn/train_normal.py:93 (each run re-samples dropout). */
+int gcnx_bernoulli_mask_dev_u8(int64_t n, float keep, uint64_t seed,
+                               uint64_t offset, const uint64_t *step_dev,
+                               uint64_t step_stride, uint8_t *mask, void *stream);
+
+/* *counter += inc on the stream (one lane).  The step counters read by
+ * gcnx_bernoulli_mask_dev_u8 and gcnx_adam_step_dev_f32 are advanced with it so
+ * that the increment is part of a captured graph. */
+int gcnx_counter_add_u64(uint64_t *counter, uint64_t inc, void *stream);
+
 /* Synthetic dense inputs (no counterpart in the reference): out[i] = lo +
  * (hi - lo) * u(seed, offset + i) with the same Philox uniform as the masks, a
  * pure function of the global element index, so that features and labels are
@@ -289,6 +310,14 @@ int gcnx_relu_dropout_bwd_f32(int64_t n, const float *y, const float *dy,
 int gcnx_adam_step_f32(int64_t n, float *w, const float *grad, float *m,
                        float *v, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int64_t t, void *stream);
+
+/* Same update with the step count t (>= 1) read from device memory when the
+ * kernel runs (the bias correction is formed on the device), for launches
+ * recorded in a HIP graph.  replaces: gcn/models.py:142,58. */
+int gcnx_adam_step_dev_f32(int64_t n, float *w, const float *grad, float *m,
+                           float *v, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, const uint64_t *t_dev,
+                           void *stream);
 
 /* ---- degree normalisation on the device -----------------------------------
  * replaces: normalize_adj / preprocess_adj, gcn/utils.py:122-135, for graphs

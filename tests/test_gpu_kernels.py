@@ -22,6 +22,19 @@ def env():
     return dict(torch=torch, oracle=oracle, ops=ops, sparse=sparse, dev=torch.device("cuda:0"))
 
 
+@pytest.fixture(autouse=True, params=["row_path", "chunk_path"])
+def spmm_path(request):
+    """Every test runs twice: with the wavefront-per-row SpMM kernel serving the
+    small matrices (the default) and with it switched off, so that the same
+    cases also exercise the chunk kernels and their fix-up pass."""
+    from gcn_amd import _lib
+    lib = _lib.load()
+    before = lib.gcnx_spmm_row_path_limit(-1)
+    lib.gcnx_spmm_row_path_limit(before if request.param == "row_path" else 0)
+    yield request.param
+    lib.gcnx_spmm_row_path_limit(before)
+
+
 def _csr_np(csr):
     return (csr.row_ptr.cpu().numpy(), csr.col_idx.cpu().numpy(), csr.val.cpu().numpy(),
             csr.input_index.cpu().numpy())
@@ -433,3 +446,36 @@ def test_gemm_dropout_on_a_matches_materialised(env, ta, M, N, K):
     got = env["ops"].gemm(at, bt, trans_a=bool(ta), a_dropout=(0.5, 77, off))
     assert torch.equal(ref, got)
     assert not env["ops"].gemm_supports_a_dropout(False, 2708, 7, 16)
+
+
+def test_device_step_counters(env):
+    """The device-counter forms of the mask and Adam kernels equal the host-
+    argument forms: offset + step * stride, and t read from memory."""
+    torch, ops = env["torch"], env["ops"]
+    dev = env["dev"]
+    ctr = ops.device_counter(dev, 0)
+    for step in (1, 2, 3):
+        ops.counter_add(ctr, 1)
+        assert int(ctr.item()) == step
+        got = ops.bernoulli_mask(10007, 0.5, 99, 4, dev, step=ctr, step_stride=2 ** 40)
+        want = ops.bernoulli_mask(10007, 0.5, 99, 4 + step * 2 ** 40, dev)
+        assert torch.equal(got, want)
+    ops.counter_add(ctr, 7)
+    assert int(ctr.item()) == 10
+    rng = np.random.RandomState(3)
+    w0 = rng.standard_normal(5003).astype(np.float32)
+    state = []
+    for t_arg in ("host", "dev"):
+        w = torch.from_numpy(w0.copy()).to(dev)
+        m, v = torch.zeros_like(w), torch.zeros_like(w)
+        tdev = ops.device_counter(dev, 0)
+        grng = np.random.RandomState(4)
+        for t in range(1, 6):
+            g = torch.from_numpy(grng.standard_normal(5003).astype(np.float32)).to(dev)
+            ops.counter_add(tdev, 1)
+            ops.adam_step(w, g, m, v, 0.01, t if t_arg == "host" else tdev, weight_decay=5e-4)
+        state.append((w.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()))
+    for x, y in zip(*state):
+        np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-8)
+    with pytest.raises(ValueError):
+        ops.adam_step(w, g, m, v, 0.01, torch.zeros(1, device=dev))

@@ -43,6 +43,7 @@ def _setup(model, dataset, epochs, hidden=16):
     F._parse([])
     F.dataset, F.model, F.epochs, F.hidden1 = dataset, model, epochs, hidden
     F.learning_rate, F.dropout, F.weight_decay, F.early_stopping, F.max_degree = 0.01, 0.5, 5e-4, 10, 3
+    F.hip_graph = False
     return F
 
 
@@ -211,3 +212,33 @@ def test_phase_trainer_and_analytic_counts():
     assert len(out["epochs"]) == 2 and all(out["phase_ms_median"][p] > 0 for p in train_phases.PHASES)
     assert out["last_stage_output"].shape == (2708, 7)
     assert np.isfinite(out["epochs"][-1]["train_loss"])
+
+
+@pytest.mark.parametrize("model,dataset", [("gcn", "cora"), ("gcn_cheby", "citeseer"), ("dense", "cora")])
+def test_hip_graph_replay_matches_eager(model, dataset):
+    """session.run replayed from a recorded HIP graph gives the numbers of the
+    eager run: same kernels, same Philox masks (the step counters live on the
+    device), same Adam updates.  25 epochs = 1 eager + 1 capture + 23 replays of
+    the training call and of the validation call."""
+    from gcn_amd import train, utils
+    data = utils.load_data(dataset)
+    traces = {}
+    for flag in (False, True):
+        F = _setup(model, dataset, 25)
+        F.early_stopping = 1000
+        F.hip_graph = flag
+        res = train.run(data=data, verbose=False)
+        sess = res["session"]
+        assert sess.hip_graph == flag
+        assert sess.graph_replays == (2 * 24 if flag else 0)
+        # the test call feeds other label/mask objects: it ran eagerly either way
+        # layer names carry a global instance counter: compare in creation order
+        weights = [v.numpy().copy() for v in res["model_obj"].vars.values()]
+        traces[flag] = (np.asarray(res["trace"])[:, :4], res["test_cost"], res["test_acc"], weights)
+    a, b = traces[False], traces[True]
+    np.testing.assert_allclose(b[0], a[0], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(b[1], a[1], rtol=2e-5)
+    assert b[2] == pytest.approx(a[2], abs=0.005)
+    assert len(a[3]) == len(b[3]) > 0
+    for x, y in zip(a[3], b[3]):
+        np.testing.assert_allclose(y, x, rtol=1e-4, atol=1e-6)

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--out", default="")
     ap.add_argument("--oracle-epochs", type=int, default=5)
+    ap.add_argument("--hip-graph", action="store_true", help="replay each session.run from a HIP graph")
     args = ap.parse_args()
     import oracle
     from oracle import model as omodel
@@ -53,6 +54,7 @@ def main():
     train.define_flags()
     F = tf.app.flags.FLAGS
     F._parse([])
+    F.hip_graph = bool(args.hip_graph)
     results = []
     for ds, model in (("cora", "gcn"), ("citeseer", "gcn"), ("pubmed", "gcn"), ("cora", "gcn_cheby"),
                       ("citeseer", "gcn_cheby"), ("pubmed", "gcn_cheby"), ("cora", "dense")):
@@ -84,7 +86,7 @@ def main():
         rec = {"dataset": ds, "model": model, "features": "synthetic" if ds == "pubmed" else "real",
                "epochs_run": res["epochs_run"], "test_acc": res["test_acc"] if ds != "pubmed" else None,
                "gpu_epoch_ms_median": ms[len(ms) // 2], "gpu_epoch_ms_min": ms[0],
-               "cpu_oracle_epoch_ms_median": sorted(cpu_ms)[len(cpu_ms) // 2], "cpu_threads": 1,
+               "cpu_oracle_epoch_ms_median": sorted(cpu_ms)[len(cpu_ms) // 2], "cpu_threads": 1, "hip_graph": bool(args.hip_graph),
                "nnz_support": [int(len(s[1])) for s in support], "wall_s": wall}
         print(json.dumps(rec), flush=True)
         results.append(rec)
