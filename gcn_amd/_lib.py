@@ -47,6 +47,7 @@ SIGNATURES = {
     "gcnx_last_error": (C.c_char_p, []),
     "gcnx_spmm_chunk_nnz": (_int, []),
     "gcnx_spmm_row_path_limit": (_i64, [_i64]),
+    "gcnx_spmm_min_chunk": (_int, [_int]),
     "gcnx_csr_from_coo_workspace_bytes": (_sz, [_i64, _i64]),
     "gcnx_csr_from_coo": (_int, [_i64, _i64, _i64, _p, _p, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "gcnx_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),

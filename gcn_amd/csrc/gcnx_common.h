@@ -18,7 +18,8 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kBlock = 256;          // 4 wavefronts per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kChunk = 512;          // nonzeros owned by one wavefront in SpMM
+constexpr int kChunk = 512;          // most nonzeros one wavefront owns in SpMM
+constexpr int kChunkUnit = 64;       // granularity of the chunk table (and the smallest chunk)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

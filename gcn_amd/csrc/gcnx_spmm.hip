@@ -1,7 +1,7 @@
 // CSR SpMM for gfx950:  C = act(alpha * A' * B + beta * C)
 //
 // Work decomposition (merge-path flavoured row split): the nonzeros are cut into
-// fixed chunks of kChunk; ONE wavefront owns one chunk, whatever rows it covers,
+// equal chunks (64..512, by matrix size); ONE wavefront owns one chunk, whatever rows it covers,
 // so a hub row with 10^5 nonzeros costs the same per wavefront as 10^5 short
 // rows.  Inside a chunk the wavefront walks the nonzeros in slot order; lane l
 // owns VEC consecutive output columns, so one nonzero is one coalesced
@@ -61,7 +61,9 @@ constexpr int kRowEndBeyond = 0x7fffffff;
 struct SpmmArgs {
   int64_t n_rows;
   int64_t nnz;
-  int64_t n_chunks;
+  int64_t n_chunks;   // chunks of `chunk` nonzeros
+  int32_t chunk;      // nonzeros one wavefront owns: kChunkUnit * chunk_mul
+  int32_t chunk_mul;  // chunk_row is tabulated every kChunkUnit nonzeros
   const int64_t *row_ptr;
   const int32_t *col_idx;
   const float *val;
@@ -132,18 +134,19 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
   const int col0 = (int)blockIdx.y * (kWave * VEC) + lane * VEC;
   const bool active = col0 < a.width;
 
-  const int64_t n0 = c * (int64_t)kChunk;
+  const int chunk = a.chunk;
+  const int64_t n0 = c * (int64_t)chunk;
   const int64_t left = a.nnz - n0;
-  const int nk = left < (int64_t)kChunk ? (int)left : kChunk;
+  const int nk = left < (int64_t)chunk ? (int)left : chunk;
 
-  int64_t r = a.chunk_row[c];
+  int64_t r = a.chunk_row[c * a.chunk_mul];
   int64_t rbase = r;
   // Lane-held window: end (relative to n0) of rows rbase .. rbase+63.
   auto load_row_ends = [&](int64_t rb) -> int {
     const int64_t rr = rb + 1 + lane;
     if (rr > a.n_rows) return kRowEndBeyond;
     const int64_t e = a.row_ptr[rr] - n0;
-    return e > (int64_t)kChunk ? kChunk + 1 : (int)e;
+    return e > (int64_t)chunk ? chunk + 1 : (int)e;
   };
   int re_v = load_row_ends(rbase);
   int re = rl_i(re_v, 0);
@@ -249,17 +252,18 @@ __global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
   const int col0 = (lane % LW) * VEC;
   const bool active = col0 < a.width;
 
-  const int64_t n0 = c * (int64_t)kChunk;
+  const int chunk = a.chunk;
+  const int64_t n0 = c * (int64_t)chunk;
   const int64_t left = a.nnz - n0;
-  const int nk = left < (int64_t)kChunk ? (int)left : kChunk;
+  const int nk = left < (int64_t)chunk ? (int)left : chunk;
 
-  int64_t r = a.chunk_row[c];
+  int64_t r = a.chunk_row[c * a.chunk_mul];
   int64_t rbase = r;
   auto load_row_ends = [&](int64_t rb) -> int {
     const int64_t rr = rb + 1 + lane;
     if (rr > a.n_rows) return kRowEndBeyond;
     const int64_t e = a.row_ptr[rr] - n0;
-    return e > (int64_t)kChunk ? kChunk + 1 : (int)e;
+    return e > (int64_t)chunk ? chunk + 1 : (int)e;
   };
   int re_v = load_row_ends(rbase);
   int re = rl_i(re_v, 0);
@@ -434,11 +438,11 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   if (c + 1 >= a.n_chunks) return;
   const int col0 = (int)blockIdx.y * (kWave * VEC) + lane * VEC;
   if (col0 >= a.width) return;
-  const int64_t r = a.chunk_row[c + 1];
+  const int64_t r = a.chunk_row[(c + 1) * a.chunk_mul];
   const int64_t start = a.row_ptr[r];
-  if (start >= (c + 1) * (int64_t)kChunk || start < c * (int64_t)kChunk) return;
+  if (start >= (c + 1) * (int64_t)a.chunk || start < c * (int64_t)a.chunk) return;
   const int64_t end = a.row_ptr[r + 1];
-  const int64_t cl = (end - 1) / kChunk;
+  const int64_t cl = (end - 1) / a.chunk;
   const float *p = a.partial + col0;
   V sum = vload<VEC>(p + ((size_t)c * 2 + 1) * a.pwidth);
   for (int64_t cc = c + 1; cc <= cl; ++cc) sum += vload<VEC>(p + (size_t)cc * 2 * a.pwidth);
@@ -461,8 +465,8 @@ __global__ void spmm_empty_kernel(const SpmmArgs a) {
   *dst = out;
 }
 
-// chunk_row[c] = last row whose first slot is <= c * kChunk (row 0 for c == 0,
-// n_rows for c == n_chunks).
+// chunk_row[c] = last row whose first slot is <= c * kChunkUnit (row 0 for
+// c == 0, n_rows for c == n_chunks).
 __global__ void chunk_table_kernel(int64_t n_rows, int64_t n_chunks,
                                    const int64_t *__restrict__ row_ptr,
                                    int32_t *__restrict__ chunk_row) {
@@ -470,7 +474,7 @@ __global__ void chunk_table_kernel(int64_t n_rows, int64_t n_chunks,
   if (c > n_chunks) return;
   if (c == 0) { chunk_row[0] = 0; return; }
   if (c == n_chunks) { chunk_row[c] = (int32_t)n_rows; return; }
-  const int64_t target = c * (int64_t)kChunk;
+  const int64_t target = c * (int64_t)kChunkUnit;
   int64_t lo = 0, hi = n_rows;  // invariant: row_ptr[lo] <= target < row_ptr[hi]
   while (hi - lo > 1) {
     const int64_t mid = lo + (hi - lo) / 2;
@@ -492,18 +496,39 @@ extern "C" void gcnx_profile_spmm_events(void *start, void *stop) {
   g_prof_stop = static_cast<hipEvent_t>(stop);
 }
 
-// Matrices with at most this many nonzeros (and a dense operand of at most 32
-// lanes) take the wavefront-per-row kernel.
-static std::atomic<int64_t> g_row_path_max_nnz{(int64_t)1 << 21};
-constexpr int64_t kRowPathMaxRows = (int64_t)1 << 20;
+// Matrices with at most this many nonzeros, at most kRowPathMaxAvg per row on
+// average and a dense operand of at most 32 lanes take the wavefront-per-row
+// kernel (its cost is the longest row, so it is kept to small, short-rowed
+// matrices: the Planetoid adjacencies and feature matrices).
+static std::atomic<int64_t> g_row_path_max_nnz{(int64_t)1 << 18};
+constexpr int64_t kRowPathMaxAvg = 64;
+
+// Nonzeros per wavefront for a matrix of nnz nonzeros: the largest power of two
+// in [kChunkUnit, kChunk] that still leaves about 8 wavefronts per SIMD
+// (256 CUs x 4 SIMDs x 8), so that small matrices are cut finely enough to
+// fill the chip and large ones amortise the per-chunk set-up.
+static std::atomic<int> g_min_chunk{kChunkUnit};
+static int chunk_for(int64_t nnz) {
+  int c = kChunkUnit;
+  while (c < kChunk && nnz / (2 * c) >= 8192) c *= 2;
+  const int lo = g_min_chunk.load();
+  return c < lo ? lo : c;
+}
+
+extern "C" int gcnx_spmm_min_chunk(int min_chunk) {
+  if (min_chunk < 0) return g_min_chunk.load();
+  int c = kChunkUnit;
+  while (c < kChunk && c < min_chunk) c *= 2;
+  return g_min_chunk.exchange(c);
+}
 
 extern "C" int64_t gcnx_spmm_row_path_limit(int64_t max_nnz) {
   return max_nnz < 0 ? g_row_path_max_nnz.load() : g_row_path_max_nnz.exchange(max_nnz);
 }
 
-extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunk; }
+extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunkUnit; }
 
-extern "C" int64_t gcnx_spmm_num_chunks(int64_t nnz) { return nnz <= 0 ? 0 : ceil_div(nnz, kChunk); }
+extern "C" int64_t gcnx_spmm_num_chunks(int64_t nnz) { return nnz <= 0 ? 0 : ceil_div(nnz, kChunkUnit); }
 
 extern "C" int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream) {
   GCNX_REQUIRE(a && chunk_row, GCNX_ERR_INVALID_ARG, "chunk_table: null argument");
@@ -521,7 +546,7 @@ static inline int32_t partial_ld(int32_t width) { return (width + 3) / 4 * 4; }
 
 extern "C" size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width) {
   if (nnz <= 0 || width <= 0) return 0;
-  return (size_t)gcnx_spmm_num_chunks(nnz) * 2 * (size_t)partial_ld(width) * sizeof(float);
+  return (size_t)ceil_div(nnz, chunk_for(nnz)) * 2 * (size_t)partial_ld(width) * sizeof(float);
 }
 
 extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
@@ -553,7 +578,9 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   SpmmArgs k;
   k.n_rows = a->n_rows;
   k.nnz = a->nnz;
-  k.n_chunks = gcnx_spmm_num_chunks(a->nnz);
+  k.chunk = chunk_for(a->nnz);
+  k.chunk_mul = k.chunk / kChunkUnit;
+  k.n_chunks = a->nnz <= 0 ? 0 : ceil_div(a->nnz, k.chunk);
   k.row_ptr = a->row_ptr;
   k.col_idx = a->col_idx;
   k.val = a->val;
@@ -617,7 +644,7 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs
   unsigned gy = 1;
   if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
-  if (lanes <= 32 && a->nnz <= g_row_path_max_nnz.load() && a->n_rows <= kRowPathMaxRows) {
+  if (lanes <= 32 && a->nnz <= g_row_path_max_nnz.load() && a->nnz <= kRowPathMaxAvg * a->n_rows) {
     const unsigned gr = (unsigned)ceil_div(a->n_rows, kWavesPerBlock);
 #define GCNX_ROW(V, L) hipLaunchKernelGGL((spmm_row_kernel<V, L>), dim3(gr), dim3(kBlock), 0, st, k)
     if (v4) {

@@ -120,6 +120,51 @@ def _merged_support(supports):
     return merged
 
 
+_IDENTITY_CHECKED = {}
+
+
+def _is_identity(csr):
+    hit = _IDENTITY_CHECKED.get(id(csr))
+    if hit is not None and hit[0] is csr:
+        return hit[1]
+    ok = csr.shape[0] == csr.shape[1] == csr.nnz
+    if ok:
+        ar = torch.arange(csr.nnz, dtype=torch.int32, device=csr.col_idx.device)
+        ok = bool(torch.equal(csr.col_idx, ar)) and bool((csr.val == 1.0).all().item())
+    _IDENTITY_CHECKED[id(csr)] = (csr, ok)
+    return ok
+
+
+def _chebyshev_recurrence():
+    return 'chebyshev_recurrence' in FLAGS and bool(FLAGS.chebyshev_recurrence)
+
+
+def _aggregate_clenshaw(supports, p, n_out, relu):
+    """sum_k T_k(L) . P_k without the matrices T_2..T_K: Clenshaw's recurrence
+
+        b_k = P_k + 2 L b_{k+1} - b_{k+2}   (k = K..1),   out = P_0 + L b_1 - b_2
+
+    with L = supports[1] (the scaled Laplacian, reference gcn/utils.py:157-158)
+    and T_0 = I, T_k = 2 L T_{k-1} - T_{k-2} (gcn/utils.py:160-167).  K products
+    over the pattern of L (nnz of A_hat) replace one product over the union of
+    the growing patterns of T_0..T_K (35x the nonzeros for Cora, K = 3).  The
+    sum is the same polynomial evaluated in fp32 on the device instead of fp64
+    on the host followed by one fp32 product, so results agree to rounding, not
+    to the bit; this mode is opt-in (FLAGS.chebyshev_recurrence)."""
+    if not _is_identity(supports[0].csr):
+        raise ValueError("chebyshev_recurrence: support[0] is not the identity")
+    lap = supports[1].csr
+    k_max = len(supports) - 1
+    part = lambda k: p[:, k * n_out:(k + 1) * n_out]
+    if k_max == 1:
+        return ops.spmm_add_autograd(lap, part(1), part(0), 1.0, relu)
+    b2 = part(k_max)                                              # b_K
+    b1 = ops.spmm_add_autograd(lap, b2, part(k_max - 1), 2.0)      # b_{K-1}
+    for k in range(k_max - 2, 0, -1):
+        b1, b2 = ops.spmm_add_autograd(lap, b1, part(k) - b2, 2.0), b1
+    return ops.spmm_add_autograd(lap, b1, part(0) - b2, 1.0, relu)
+
+
 def _aggregate(run, supports, p, n_out, relu):
     """act(sum_i A_i . P_i) with P_i = p[:, i*n_out:(i+1)*n_out]."""
     if len(supports) == 1:
@@ -128,6 +173,8 @@ def _aggregate(run, supports, p, n_out, relu):
     for s in supports:
         if s.mask is not None:
             raise NotImplementedError("dropout on a support matrix")
+    if _chebyshev_recurrence():
+        return _aggregate_clenshaw(supports, p, n_out, relu)
     merged = _merged_support(supports)
     n = p.shape[0]
     return ops.spmm_autograd(merged, p.contiguous().view(n * len(supports), n_out), None, 1.0, relu)

@@ -104,6 +104,36 @@ def spmm_autograd(a, b, mask=None, mask_scale=1.0, relu=False):
     return _SpmmFn.apply(b, a, mask, mask_scale, relu)
 
 
+class _SpmmAddFn(torch.autograd.Function):
+    """y = act(alpha * A @ b + c) in one launch (c is copied into the output and
+    accumulated onto).  Gradients: d b = alpha * A^T dy', d c = dy', with dy' the
+    relu-gated dy."""
+
+    @staticmethod
+    def forward(ctx, b, c, a, alpha, relu):
+        y = c.clone(memory_format=torch.contiguous_format)
+        spmm(a, b, out=y, alpha=alpha, beta=1.0, relu=relu)
+        ctx.a = a
+        ctx.alpha = alpha
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            dy = relu_dropout_bwd(y, dy)
+        db = spmm(ctx.a.transpose(), dy, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
+        return db, (dy if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def spmm_add_autograd(a, b, c, alpha=1.0, relu=False):
+    return _SpmmAddFn.apply(b.contiguous(), c, a, float(alpha), relu)
+
+
 # ------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
          gate_scale=1.0, a_dropout=None):

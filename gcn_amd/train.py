@@ -34,6 +34,9 @@ def define_flags():
     flags.DEFINE_integer('max_degree', 3, 'Maximum Chebyshev polynomial degree.')
     flags.DEFINE_integer('seed', 123, 'Random seed (the reference hard-codes 123).')
     flags.DEFINE_string('report', '', 'Optional path of a JSON run report.')
+    flags.DEFINE_boolean('chebyshev_recurrence', False,
+                         'gcn_cheby: evaluate sum_k T_k(L) P_k by Clenshaw recurrence over the pattern of L '
+                         'instead of the explicit T_k matrices (same polynomial, fp32 rounding differs).')
     flags.DEFINE_boolean('hip_graph', False, 'Record each distinct session.run in a HIP graph and replay it.')
 
 

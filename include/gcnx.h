@@ -71,8 +71,9 @@ typedef struct gcnx_dropout {
 
 int gcnx_abi_version(void);
 const char *gcnx_last_error(void);
-/* Number of nonzeros one wavefront owns in the SpMM kernels (the unit of the
- * chunk table below). */
+/* Granularity of the chunk table below, in nonzeros.  One wavefront of the SpMM
+ * kernels owns 1, 2, 4 or 8 such units, chosen from the matrix size at each
+ * call. */
 int gcnx_spmm_chunk_nnz(void);
 
 /* ---- CSR construction ---------------------------------------------------
@@ -130,6 +131,10 @@ size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width);
  * kernel is used; returns the previous value; a negative argument only reads.
  * 0 sends every matrix down the chunk kernels. */
 int64_t gcnx_spmm_row_path_limit(int64_t max_nnz);
+/* Tuning knob (process-wide): smallest number of nonzeros per wavefront in the
+ * chunk kernels (rounded up to 64, 128, 256 or 512; default 64, 512 restores
+ * one fixed chunk size); returns the previous value; negative only reads. */
+int gcnx_spmm_min_chunk(int min_chunk);
 int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       const float *B, int64_t ldb, float *C, int64_t ldc,
                       int32_t width, float alpha, float beta,

@@ -355,10 +355,10 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert _lib.load().gcnx_abi_version() == 1
-    assert _lib.load().gcnx_spmm_chunk_nnz() == 512
+    assert _lib.load().gcnx_spmm_chunk_nnz() == 64
     # pure host-side queries work without a GPU
-    assert _lib.load().gcnx_spmm_num_chunks(1025) == 3
-    assert _lib.load().gcnx_spmm_workspace_bytes(1025, 7) == 3 * 2 * 8 * 4
+    assert _lib.load().gcnx_spmm_num_chunks(1025) == 17
+    assert _lib.load().gcnx_spmm_workspace_bytes(1025, 7) == 17 * 2 * 8 * 4
 
 
 def test_product_never_imports_the_oracle():

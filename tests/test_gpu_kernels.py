@@ -22,17 +22,24 @@ def env():
     return dict(torch=torch, oracle=oracle, ops=ops, sparse=sparse, dev=torch.device("cuda:0"))
 
 
-@pytest.fixture(autouse=True, params=["row_path", "chunk_path"])
+@pytest.fixture(autouse=True, params=["default", "chunk64", "chunk512"])
 def spmm_path(request):
-    """Every test runs twice: with the wavefront-per-row SpMM kernel serving the
-    small matrices (the default) and with it switched off, so that the same
-    cases also exercise the chunk kernels and their fix-up pass."""
+    """Every test runs three times: with the default dispatch (wavefront-per-row
+    kernel for the small matrices, chunk size by matrix size), with the row kernel
+    switched off (chunk kernels with 64-nonzero chunks: many rows cut by chunk
+    boundaries, the fix-up pass does most stores) and with 512-nonzero chunks
+    (the configuration the large graphs run: several 64-wide batches per
+    wavefront)."""
     from gcn_amd import _lib
     lib = _lib.load()
-    before = lib.gcnx_spmm_row_path_limit(-1)
-    lib.gcnx_spmm_row_path_limit(before if request.param == "row_path" else 0)
+    row_before = lib.gcnx_spmm_row_path_limit(-1)
+    chunk_before = lib.gcnx_spmm_min_chunk(-1)
+    if request.param != "default":
+        lib.gcnx_spmm_row_path_limit(0)
+        lib.gcnx_spmm_min_chunk(64 if request.param == "chunk64" else 512)
     yield request.param
-    lib.gcnx_spmm_row_path_limit(before)
+    lib.gcnx_spmm_row_path_limit(row_before)
+    lib.gcnx_spmm_min_chunk(chunk_before)
 
 
 def _csr_np(csr):

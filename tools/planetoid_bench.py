@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--oracle-epochs", type=int, default=5)
     ap.add_argument("--hip-graph", action="store_true", help="replay each session.run from a HIP graph")
+    ap.add_argument("--chebyshev-recurrence", action="store_true",
+                    help="gcn_cheby by Clenshaw recurrence over the pattern of L")
+    ap.add_argument("--only", default="", help="run one configuration, e.g. pubmed:gcn_cheby")
     args = ap.parse_args()
     import oracle
     from oracle import model as omodel
@@ -55,9 +58,12 @@ def main():
     F = tf.app.flags.FLAGS
     F._parse([])
     F.hip_graph = bool(args.hip_graph)
+    F.chebyshev_recurrence = bool(args.chebyshev_recurrence)
     results = []
     for ds, model in (("cora", "gcn"), ("citeseer", "gcn"), ("pubmed", "gcn"), ("cora", "gcn_cheby"),
                       ("citeseer", "gcn_cheby"), ("pubmed", "gcn_cheby"), ("cora", "dense")):
+        if args.only and args.only != "%s:%s" % (ds, model):
+            continue
         F.dataset, F.model, F.epochs = ds, model, args.epochs
         data = pubmed_with_synthetic_features() if ds == "pubmed" else utils.load_data(ds)
         t0 = time.time()
@@ -87,6 +93,7 @@ def main():
                "epochs_run": res["epochs_run"], "test_acc": res["test_acc"] if ds != "pubmed" else None,
                "gpu_epoch_ms_median": ms[len(ms) // 2], "gpu_epoch_ms_min": ms[0],
                "cpu_oracle_epoch_ms_median": sorted(cpu_ms)[len(cpu_ms) // 2], "cpu_threads": 1, "hip_graph": bool(args.hip_graph),
+               "chebyshev_recurrence": bool(args.chebyshev_recurrence),
                "nnz_support": [int(len(s[1])) for s in support], "wall_s": wall}
         print(json.dumps(rec), flush=True)
         results.append(rec)
