@@ -11,6 +11,9 @@
 // H^T * dP, reduced over all nodes) is split along K across workgroups; each
 // split writes its tile to the workspace and gemm_reduce_kernel adds the tiles
 // in split order, so the sum is reproducible.
+#include <algorithm>
+#include <cstdlib>
+
 #include "gcnx_common.h"
 #include "gcnx_philox.h"
 
@@ -469,6 +472,284 @@ __global__ __launch_bounds__(kBlock) void gemm_small_k_kernel(const GemmArgs g) 
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same product (K <= 16, wide output) on the matrix pipe: with the FMAs on
+// the VALU the kernel above spends about as long computing as streaming; here
+// the VALU only runs the epilogue.  One wavefront owns 32 rows and walks the
+// output in 32 x 32 tiles (v_mfma_f32_32x32x2_f32, 8 steps cover K = 16).
+// A is read as it lies in memory, one 16-byte load per 8 values of k:
+// lane (i = lane & 31, h = lane >> 5) holds A[i][4h..4h+3] and A[i][8+4h..8+4h+3],
+// so step s = 4*half + j multiplies k = 8*half + 4h + j; the op(B) fragments
+// (kept in registers for the whole kernel) use the same k numbering.  The sum
+// over k inside one accumulator is order-free, so this is the same fp32 result
+// up to the order of the 16 terms.  A tile is stored with 128-byte row
+// segments (lanes 0..31 one row, lanes 32..63 the row 4 below).
+// ---------------------------------------------------------------------------
+typedef float __attribute__((ext_vector_type(16))) f16v_;
+
+template <bool TB>
+__global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const GemmArgs g) {
+  constexpr int NT = 8;  // 32-column tiles of one 256-column slab
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t n0 = (int64_t)blockIdx.y * 256;
+  float bf[NT][8];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = 8 * (s >> 2) + 4 * lh + (s & 3);
+      const int64_t n = n0 + 32 * t + li;
+      float v = 0.0f;
+      if (k < g.K && n < g.N) v = TB ? g.B[n * g.ldb + k] : g.B[(int64_t)k * g.ldb + n];
+      bf[t][s] = v;
+    }
+  const bool vec_a = (g.K == 16) && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t r0 = wave * 32; r0 < g.M; r0 += nwaves * 32) {
+    float af[8];
+    {
+      const int64_t row = r0 + li;
+      f4v a0 = f4v{0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+      if (row < g.M) {
+        const float *ap = g.A + row * g.lda;
+        if (vec_a) {
+          a0 = *reinterpret_cast<const f4v *>(ap + 4 * lh);
+          a1 = *reinterpret_cast<const f4v *>(ap + 8 + 4 * lh);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (4 * lh + j < g.K) a0[j] = ap[4 * lh + j];
+            if (8 + 4 * lh + j < g.K) a1[j] = ap[8 + 4 * lh + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { af[j] = a0[j]; af[4 + j] = a1[j]; }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t col = n0 + 32 * t + li;
+      if (n0 + 32 * t >= g.N) break;
+      // the gate / old values of this tile travel while its MFMAs run
+      float gt[16], old[16];
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int64_t row = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+        gt[rg] = 1.0f;
+        old[rg] = 0.0f;
+        if (row < g.M && col < g.N) {
+          if (g.gate) gt[rg] = g.gate[row * g.ldgate + col];
+          if (g.beta != 0.0f) old[rg] = g.C[row * g.ldc + col];
+        }
+      }
+      f16v_ acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[t][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int64_t row = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+        if (row < g.M && col < g.N) {
+          float o = g.alpha * acc[rg] + g.beta * old[rg];
+          if (g.relu) o = fmaxf(o, 0.0f);
+          if (g.gate) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
+          g.C[row * g.ldc + col] = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Skinny output, no transposes:  C[M, N<=16] = A[M,K] * B[K,N]  with K a
+// multiple of 64 up to 256 (H' * W2 with N = the class count).  Bound by
+// streaming A once, so A is read the way HBM likes it: one wavefront load
+// instruction = one full row segment of up to 1 KiB, marked non-temporal
+// (streaming reads measure 7.0 TB/s that way against 6.2 TB/s plain and
+// 4.6 TB/s when an instruction touches 16 rows x 64 bytes).  v_mfma_f32_16x16x4_f32
+// wants lane (i = lane & 15, q = lane >> 4) to hold A[row i][k], so the 16 rows
+// of a pass go through a wavefront-private LDS tile (row pitch K + 4 floats):
+// written as loaded, read back as 16-byte fragments A[i][16s + 4q .. +3]; MFMA
+// (s, j) multiplies k = 16s + 4q + j and the B fragments (registers) use the
+// same numbering.  No workgroup barrier: a wavefront only touches its own tile.
+// The loads of the next two passes are in flight while this pass multiplies.
+// ---------------------------------------------------------------------------
+#ifndef GCNX_SKINNY_DIST
+#define GCNX_SKINNY_DIST 2
+#endif
+template <int KS>   // K <= 16 * KS, KS = 4, 8, 16
+__global__ __launch_bounds__(kBlock, 1) void gemm_skinny_n_kernel(const GemmArgs g) {
+  constexpr int KMAX = 16 * KS;
+  constexpr int PITCH = KMAX + 4;
+  constexpr int LPR = KMAX / 4;          // lanes that cover one row with 16-byte loads
+  constexpr int RPI = kWave / LPR;       // rows one load instruction covers (1, 2 or 4)
+  constexpr int NLD = 16 / RPI;          // load instructions per 16-row pass
+  __shared__ float tile[kWavesPerBlock][16 * PITCH];
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float *const my = tile[wid];
+  const int ks = (int)(g.K / 16);
+  float bf[KS][4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 16 * s + 4 * lq + j;
+      bf[s][j] = (s < ks && li < g.N) ? g.B[(int64_t)k * g.ldb + li] : 0.0f;
+    }
+  const int lrow = lane / LPR, lcol = (lane % LPR) * 4;
+  const bool col_ok = lcol < g.K;
+  const bool fast_store = g.N == 16 && g.beta == 0.0f && !g.gate && (g.ldc % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  // DIST passes of loads are kept in flight (one register set each)
+  constexpr int DIST = GCNX_SKINNY_DIST;
+  f4v ld[DIST][NLD];
+  auto issue_loads = [&](int64_t r0, f4v (&dst)[NLD]) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int64_t row = r0 + u * RPI + lrow;
+      dst[u] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < g.M && col_ok)
+        dst[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(g.A + row * g.lda + lcol));
+    }
+  };
+  auto pass = [&](int64_t r0, f4v (&cur)[NLD]) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      *reinterpret_cast<f4v *>(my + (u * RPI + lrow) * PITCH + lcol) = cur[u];
+    const int64_t rn = r0 + DIST * nwaves * 16;
+    if (rn < g.M) issue_loads(rn, cur);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // two accumulator chains so that consecutive MFMAs do not wait on each other
+    f4v acc = f4v{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc;
+#pragma unroll
+    for (int s = 0; s < KS; s += 2) {
+      if (s < ks) {
+        const f4v a = *reinterpret_cast<const f4v *>(my + li * PITCH + 16 * s + 4 * lq);
+        const f4v a1 = *reinterpret_cast<const f4v *>(my + li * PITCH + 16 * (s + 1) + 4 * lq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bf[s][j], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bf[s + 1][j], acc1, 0, 0, 0);
+        }
+      }
+    }
+    acc += acc1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // D layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+    if (fast_store) {
+      // C rows are 64 bytes: turn the tile through LDS so that each lane stores
+      // 16 contiguous bytes (a wavefront store covers whole 128-byte lines)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float o = g.alpha * acc[rg];
+        if (g.relu) o = fmaxf(o, 0.0f);
+        my[(4 * lq + rg) * 16 + li] = o;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int64_t gm = r0 + (lane >> 2);
+      const f4v o = *reinterpret_cast<const f4v *>(my + lane * 4);
+      if (gm < g.M) *reinterpret_cast<f4v *>(g.C + gm * g.ldc + (lane & 3) * 4) = o;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int64_t gm = r0 + 4 * lq + rg;
+        if (gm < g.M && li < g.N) {
+          float *dst = g.C + gm * g.ldc + li;
+          *dst = gemm_epilogue(g, acc[rg], dst, gm, li);
+        }
+      }
+    }
+  };
+  const int64_t step = nwaves * 16;
+  int64_t r0 = wave * 16;
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (r0 + d * step < g.M) issue_loads(r0 + d * step, ld[d]);
+  for (; r0 < g.M; r0 += DIST * step) {
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+      if (r0 + d * step < g.M) pass(r0 + d * step, ld[d]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Skinny weight gradient:  C[M, N<=16] = A^T * B  with A stored [K, M], B
+// stored [K, N], K = the node dimension, split along K over grid.z
+// (H'^T * dP2).  One wavefront owns 64 columns of A: lane (i, q) loads
+// A[k + q][m0 + 4i .. +3] (16 bytes; a wavefront reads 4 rows x 256 bytes) and
+// B[k + q][i]; MFMA j of the group forms the 16 x 16 tile of output rows
+// m0 + 4i + j.  Eight groups (32 rows of A and B) are in flight per pass.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gemm_skinny_tn_kernel(const GemmArgs g) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t m0 = ((int64_t)blockIdx.x * kWavesPerBlock + wid) * 64;
+  if (m0 >= g.M) return;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  const bool m_ok = m0 + 4 * li < g.M;   // M % 4 == 0
+  const bool n_ok = li < g.N;
+  f4v acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t kk = kbeg; kk < kend; kk += 4 * U) {
+    f4v a[U];
+    float b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = kk + 4 * u + lq;
+      a[u] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      b[u] = 0.0f;
+      if (k < kend) {
+        if (m_ok) a[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(g.A + k * g.lda + m0 + 4 * li));
+        if (n_ok) b[u] = g.B[k * g.ldb + li];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u], acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int64_t gm = m0 + 4 * (4 * lq + rg) + j;
+      if (gm >= g.M || !n_ok) continue;
+      if (g.splits > 1) {
+        g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + li] = acc[j][rg];
+      } else {
+        float *dst = g.C + gm * g.ldc + li;
+        *dst = gemm_epilogue(g, acc[j][rg], dst, gm, li);
+      }
+    }
+}
+
+static bool skinny_tn_shape(int64_t M, int64_t N, int64_t K) {
+  return N >= 1 && N <= 16 && M >= 64 && M % 4 == 0 && K >= 4096;
+}
+
+static int skinny_tn_splits(int64_t M, int64_t K) {
+  const int64_t blocks = ceil_div(M, 256);
+  int64_t s = 1024 / blocks;
+  const int64_t max_s = ceil_div(K, 512);
+  if (s > max_s) s = max_s;
+  if (s > 65535) s = 65535;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 // Shapes served by gemm_mfma_tn_kernel (transposed A, plain B).
 static bool tn_mfma_shape(int64_t M, int64_t N, int64_t K) {
   return M >= 64 && M % 128 == 0 && K >= 4096 && (N % 128 == 0 || N <= 32);
@@ -508,8 +789,11 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
                                             int64_t K) {
   (void)trans_a; (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int s = (trans_a && !trans_b && tn_mfma_shape(M, N, K)) ? tn_mfma_splits(M, N, K)
-                                                                : choose_splits(M, N, K);
+  // the largest split count any kernel that may serve this shape would use
+  // (which one runs also depends on alignment and on the fused options)
+  int s = choose_splits(M, N, K);
+  if (trans_a && !trans_b && skinny_tn_shape(M, N, K)) s = std::max(s, skinny_tn_splits(M, K));
+  if (trans_a && !trans_b && tn_mfma_shape(M, N, K)) s = std::max(s, tn_mfma_splits(M, N, K));
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -588,6 +872,15 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   const bool small_k = !trans_a && !want_adrop && K >= 1 && K <= 32 && N >= 64 && (N % 4 == 0) &&
                        M >= 1024 && (ldc % 4 == 0) && aligned16(C) &&
                        (!gate || ((ldgate % 4 == 0) && aligned16(gate)));
+  if (small_k && K <= 16 && N % 32 == 0) {
+    int64_t blocks = ceil_div(ceil_div(M, 32), kWavesPerBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));
+    if (trans_b) hipLaunchKernelGGL((gemm_small_k_mfma_kernel<true>), grid, dim3(kBlock), 0, st, g);
+    else hipLaunchKernelGGL((gemm_small_k_mfma_kernel<false>), grid, dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
   if (small_k) {
     int64_t blocks = ceil_div(ceil_div(M, 2), kWavesPerBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -600,6 +893,41 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
       else hipLaunchKernelGGL((gemm_small_k_kernel<32, false>), grid, dim3(kBlock), 0, st, g);
     }
     GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+
+  // skinny output (the class dimension): stream A once, no LDS
+  const bool skinny_n = !trans_a && !trans_b && !want_adrop && N <= 16 && K >= 64 && K <= 256 &&
+                        K % 16 == 0 && M >= 1024 && (lda % 4 == 0) && aligned16(A);
+  if (skinny_n) {
+    int64_t blocks = ceil_div(ceil_div(M, 16), kWavesPerBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const dim3 grid((unsigned)blocks);
+    if (K <= 64) hipLaunchKernelGGL((gemm_skinny_n_kernel<4>), grid, dim3(kBlock), 0, st, g);
+    else if (K <= 128) hipLaunchKernelGGL((gemm_skinny_n_kernel<8>), grid, dim3(kBlock), 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_n_kernel<16>), grid, dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+  const bool skinny_tn = trans_a && !trans_b && !want_adrop && skinny_tn_shape(M, N, K) &&
+                         (lda % 4 == 0) && aligned16(A);
+  if (skinny_tn) {
+    const int sp = skinny_tn_splits(M, K);
+    if (sp > 1) {
+      const size_t need = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+      GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
+                   "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
+      g.partial = static_cast<float *>(ws);
+      g.splits = sp;
+      g.k_per_split = ceil_div(ceil_div(K, sp), 32) * 32;
+    }
+    hipLaunchKernelGGL(gemm_skinny_tn_kernel, dim3((unsigned)ceil_div(M, 256), 1u, (unsigned)g.splits),
+                       dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+    if (g.splits > 1) {
+      hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
+      GCNX_CHECK_LAUNCH();
+    }
     return GCNX_OK;
   }
 

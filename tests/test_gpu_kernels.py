@@ -216,6 +216,11 @@ def test_spmm_reproducible_and_strided(env):
     (1, 0, 128, 7, 5000), (1, 0, 384, 128, 9999), (1, 0, 256, 32, 4100),
     (0, 0, 5000, 16, 256), (0, 0, 5001, 7, 64), (0, 1, 5000, 256, 16), (0, 1, 777, 128, 64), (0, 1, 4096, 20, 128),
     (0, 1, 5003, 260, 7), (0, 0, 2049, 512, 32), (0, 0, 1500, 64, 3), (0, 1, 9000, 1024, 20),
+    # small K on the matrix pipe (K <= 16, N % 32 == 0), ragged rows, K not a multiple of 4, two slabs
+    (0, 1, 5003, 96, 12), (0, 0, 4099, 512, 16), (0, 0, 1025, 64, 5),
+    # skinny outputs: N <= 16 streaming kernels (plain and transposed A)
+    (0, 0, 4099, 16, 128), (0, 0, 1024, 3, 256), (0, 0, 70001, 16, 256), (1, 0, 260, 16, 40000),
+    (1, 0, 64, 1, 4096), (1, 0, 256, 6, 123457),
 ])
 def test_gemm_matches_oracle(env, ta, tb, M, N, K):
     torch = env["torch"]
@@ -451,7 +456,13 @@ def test_gemm_dropout_on_a_matches_materialised(env, ta, M, N, K):
     ad = env["ops"].dropout_philox(at.view(-1), 0.5, 77, off).view(at.shape)
     ref = env["ops"].gemm(ad, bt, trans_a=bool(ta))
     got = env["ops"].gemm(at, bt, trans_a=bool(ta), a_dropout=(0.5, 77, off))
-    assert torch.equal(ref, got)
+    if N > 16:
+        assert torch.equal(ref, got)            # the same kernel serves both calls
+    else:
+        # the stored operand goes through the skinny streaming kernel, which sums
+        # k in another order: same terms, fp32 rounding differs
+        mag = (ad.abs().t() if ta else ad.abs()).double() @ bt.abs().double()
+        assert float(((ref - got).abs().double() / mag).max()) <= RTOL
     assert not env["ops"].gemm_supports_a_dropout(False, 2708, 7, 16)
 
 
