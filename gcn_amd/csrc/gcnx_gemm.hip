@@ -158,14 +158,15 @@ typedef float __attribute__((ext_vector_type(16))) f16v;
 
 constexpr int MB = 128, KB = 16;
 
-// BN = 128: wavefront w owns rows [32w, 32w+32) and all 128 columns (four
-// accumulator tiles).  BN = 32: the class-dimension / skinny case (N <= 32,
+// BN = 128 / 256: wavefront w owns rows [32w, 32w+32) and all BN columns (four
+// or eight accumulator tiles); 256 is used when N allows it, so that A is
+// streamed (and its fused dropout regenerated) once per 256 output columns.  BN = 32: the class-dimension / skinny case (N <= 32,
 // columns beyond N read as zero, one tile per wavefront); such products are
 // bound by streaming A (or writing C), the matrix pipe has room to spare.
 // TB: B is stored [N, K] (the product with a transposed weight matrix); it is
 // transposed while it is staged, so the inner loop is the same.
 template <int BN, bool TB>
-__global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(const GemmArgs g) {
   // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
   // stride-17 words (conflict free), lanes 32..63 the next k.
   constexpr int NT = BN / 32;
@@ -187,8 +188,9 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
   // MFMAs of K-step i and land in registers; they are written to LDS (A with
   // its dropout applied) after those MFMAs have been issued.
   constexpr int NB_S = (KB * BN) / kBlock;   // scalar B elements per thread (generic paths)
-  f4v ra[2], rb[2];
-  float rbs[NB_S];
+  constexpr int NB_V = NB_S / 4;             // 16-byte B pieces per thread (plain B, BN >= 128)
+  f4v ra[2], rb[NB_V > 0 ? NB_V : 1];
+  float rbs[(TB || BN < 128) ? NB_S : 1];
   auto load_tiles = [&](int64_t kk) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
       ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
       if (gm < g.M) ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
     }
-    if constexpr (!TB && BN == 128) {
+    if constexpr (!TB && BN >= 128) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NB_V; ++i) {
         const int e = tid + i * kBlock;
-        const int k = e >> 5, q = e & 31;
+        const int k = e / (BN / 4), q = e % (BN / 4);
         rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
       }
     } else if constexpr (!TB) {
@@ -231,11 +233,11 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
       float *d = As + m * (KB + 1) + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    if constexpr (!TB && BN == 128) {
+    if constexpr (!TB && BN >= 128) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NB_V; ++i) {
         const int e = tid + i * kBlock;
-        const int k = e >> 5, q = e & 31;
+        const int k = e / (BN / 4), q = e % (BN / 4);
         *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = rb[i];
       }
     } else if constexpr (!TB) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
     if (kk + KB < g.K) load_tiles(kk + KB);
 #pragma unroll
     for (int k2 = 0; k2 < KB; k2 += 2) {
-      if constexpr (BN == 128) {
+      if constexpr (BN >= 128) {
         const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -295,19 +297,20 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_kernel(const GemmArgs g) 
 // grid.z.  The A operand of v_mfma_f32_32x32x2_f32 wants A_op[i][k] = A[k][i]:
 // for a fixed k the 32 values are contiguous in memory, so both operands are
 // staged in LDS exactly as they lie in HBM ([k][m] and [k][n]) and fragment
-// reads are conflict free.  Block tile 128 x BN: BN = 128 -> wavefronts 2 x 2,
-// each 64 x 64 (four accumulator tiles); BN = 32 -> wavefronts 4 x 1, each
+// reads are conflict free.  Block tile 128 x BN: BN = 128 / 256 -> wavefronts
+// 2 x 2, each 64 x 64 / 64 x 128 (four / eight accumulator tiles); BN = 32 -> wavefronts 4 x 1, each
 // 32 x 32 (the class-dimension case, N <= 32, columns beyond N read as zero).
 // Every split writes its tile to the workspace; gemm_reduce_kernel adds the
 // splits in order.
 // ---------------------------------------------------------------------------
 template <int BN>
-__global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_tn_kernel(const GemmArgs g) {
   constexpr int BM = 128, BK = 16;
-  constexpr int WN = BN == 128 ? 2 : 1;          // wavefronts along N
+  constexpr int WN = BN >= 128 ? 2 : 1;          // wavefronts along N
   constexpr int WM = 4 / WN;                     // wavefronts along M
   constexpr int TMW = BM / (32 * WM);            // accumulator tiles per wavefront along M
   constexpr int TNW = BN / (32 * WN);
+  constexpr int NBV = BN >= 128 ? BN / 64 : 1;   // 16-byte B pieces per thread
   __shared__ float As[BK * BM];
   __shared__ float Bs[BK * BN];
   const int tid = threadIdx.x;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
 
   // software pipeline as in gemm_mfma_kernel: next K-step's tiles travel in
   // registers while this K-step's MFMAs run
-  f4v ra[2], rb[2];
+  f4v ra[2], rb[NBV];
   float rbs[2];
   auto load_tiles = [&](int64_t kk) {
 #pragma unroll
@@ -338,11 +341,16 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
       const int k = e >> 5, q = e & 31;
       ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
       if (kk + k < kend) ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
-      if constexpr (BN == 128) {
+      if constexpr (BN < 128)
+        rbs[i] = (kk + k < kend && n0 + q < g.N) ? g.B[(kk + k) * g.ldb + n0 + q] : 0.0f;
+    }
+    if constexpr (BN >= 128) {
+#pragma unroll
+      for (int i = 0; i < NBV; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e / (BN / 4), q = e % (BN / 4);
         rb[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
         if (kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
-      } else {
-        rbs[i] = (kk + k < kend && n0 + q < g.N) ? g.B[(kk + k) * g.ldb + n0 + q] : 0.0f;
       }
     }
   };
@@ -354,10 +362,14 @@ __global__ __launch_bounds__(kBlock, 3) void gemm_mfma_tn_kernel(const GemmArgs 
       f4v v = ra[i];
       if (g.adrop_keep < 1.0f && kk + k < kend) v = drop4(g, v, kk + k, m0 + q * 4);
       *reinterpret_cast<f4v *>(As + k * BM + q * 4) = v;
-      if constexpr (BN == 128) {
+      if constexpr (BN < 128) Bs[k * BN + q] = rbs[i];
+    }
+    if constexpr (BN >= 128) {
+#pragma unroll
+      for (int i = 0; i < NBV; ++i) {
+        const int e = tid + i * kBlock;
+        const int k = e / (BN / 4), q = e % (BN / 4);
         *reinterpret_cast<f4v *>(Bs + k * BN + q * 4) = rb[i];
-      } else {
-        Bs[k * BN + q] = rbs[i];
       }
     }
   };
@@ -756,7 +768,7 @@ static bool tn_mfma_shape(int64_t M, int64_t N, int64_t K) {
 }
 
 static int tn_mfma_splits(int64_t M, int64_t N, int64_t K) {
-  const int64_t bn = N % 128 == 0 ? 128 : 32;
+  const int64_t bn = N % 256 == 0 ? 256 : N % 128 == 0 ? 128 : 32;
   const int64_t tiles = (M / 128) * ceil_div(N, bn);
   int64_t s = 2048 / tiles;
   const int64_t max_s = ceil_div(K, 1024);
@@ -939,6 +951,12 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
     const int64_t mt = ceil_div(M, MB);
     GCNX_REQUIRE(mt <= 0x7fffffffll && N / 128 <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
+    if (N % 256 == 0 && !trans_b) {
+      // the whole 256-column slab per workgroup: A (and its dropout) is read once per slab
+      hipLaunchKernelGGL((gemm_mfma_kernel<256, false>), dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g);
+      GCNX_CHECK_LAUNCH();
+      return GCNX_OK;
+    }
     const dim3 grid((unsigned)mt, (unsigned)(N % 128 == 0 ? N / 128 : 1));
     if (N % 128 == 0) {
       if (trans_b) hipLaunchKernelGGL((gemm_mfma_kernel<128, true>), grid, dim3(kBlock), 0, st, g);
@@ -963,7 +981,12 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
       g.splits = sp;
       g.k_per_split = ceil_div(ceil_div(K, sp), 16) * 16;
     }
-    if (N % 128 == 0) {
+    if (N % 256 == 0) {
+      // 128 x 256 tiles: each workgroup reads its slice of A (and regenerates its
+      // dropout) once per 256 output columns
+      hipLaunchKernelGGL((gemm_mfma_tn_kernel<256>), dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
+                         dim3(kBlock), 0, st, g);
+    } else if (N % 128 == 0) {
       hipLaunchKernelGGL((gemm_mfma_tn_kernel<128>), dim3((unsigned)(M / 128), (unsigned)(N / 128), (unsigned)g.splits),
                          dim3(kBlock), 0, st, g);
     } else {
