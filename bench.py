@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--hang-dump", type=int, default=0,
                     help="with --verbose: dump all Python stacks and exit after this many seconds")
+    ap.add_argument("--halo-mode", default="auto", choices=["auto", "exchange", "recompute"],
+                    help="several GPUs: send the hidden-width halo rows, or recompute them where they are needed")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
                     "ranks sharing one GPU)")
     args = ap.parse_args()
@@ -186,7 +188,7 @@ def main():
 
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                                 row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
-                                slab_cols=args.slab_cols or None)
+                                slab_cols=args.slab_cols or None, halo_mode=args.halo_mode)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -207,7 +209,7 @@ def main():
             return getattr(ops, name)
 
         def spmm(self, aa, b, **kw):
-            if Timed.armed and b.shape[1] == args.hidden and len(ev_used) < n_ev and (world == 1):
+            if Timed.armed and b.shape[1] == args.hidden and len(ev_used) < n_ev:
                 s, e = ev[len(ev_used)]
                 ops.profile_spmm_events(s, e)
                 out = real_spmm(aa, b, **kw)
@@ -258,6 +260,7 @@ def main():
                                                                 args.features, args.hidden, args.classes),
                 "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
                 "halo_rows_rank0": (model.plan.n_halo if model.plan is not None else 0),
+                "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
                 "spmm_per_step": "2 x width %d + 2 x width %d" % (args.hidden, args.classes),
             },
             "epoch_ms": dt / args.steps * 1e3,

@@ -43,6 +43,13 @@ struct GemmArgs {
   uint64_t adrop_seed;
   uint64_t adrop_offset;
   int64_t adrop_ld;
+  // nullable: row i of A is row adrop_rows[i] of the matrix the mask is defined
+  // on (A holds a gathered subset of its rows)
+  const int32_t *adrop_rows;
+  // nullable: the gate as one bit per element (bit n % 32 of word
+  // gate_bits[m * ldbits + n / 32] set <=> keep)
+  const uint32_t *gate_bits;
+  int64_t ldbits;
 };
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
@@ -64,6 +71,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs &g, float acc, flo
   if (g.beta != 0.0f) out += g.beta * *dst;
   if (g.relu) out = fmaxf(out, 0.0f);
   if (g.gate) out = g.gate[gm * g.ldgate + gn] > 0.0f ? out * g.gate_scale : 0.0f;
+  if (g.gate_bits) out = ((g.gate_bits[gm * g.ldbits + (gn >> 5)] >> (gn & 31)) & 1u) ? out * g.gate_scale : 0.0f;
   return out;
 }
 
@@ -229,7 +237,8 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
       const int e = tid + i * kBlock;
       const int m = e >> 2, q = e & 3;
       f4v v = ra[i];
-      if (g.adrop_keep < 1.0f && m0 + m < g.M) v = drop4(g, v, m0 + m, kk + q * 4);
+      if (g.adrop_keep < 1.0f && m0 + m < g.M)
+        v = drop4(g, v, g.adrop_rows ? (int64_t)g.adrop_rows[m0 + m] : m0 + m, kk + q * 4);
       float *d = As + m * (KB + 1) + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -554,6 +563,8 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
         old[rg] = 0.0f;
         if (row < g.M && col < g.N) {
           if (g.gate) gt[rg] = g.gate[row * g.ldgate + col];
+          if (g.gate_bits)
+            gt[rg] = ((g.gate_bits[row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? 1.0f : 0.0f;
           if (g.beta != 0.0f) old[rg] = g.C[row * g.ldc + col];
         }
       }
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
         if (row < g.M && col < g.N) {
           float o = g.alpha * acc[rg] + g.beta * old[rg];
           if (g.relu) o = fmaxf(o, 0.0f);
-          if (g.gate) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
+          if (g.gate || g.gate_bits) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
           g.C[row * g.ldc + col] = o;
         }
       }
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(kBlock, 1) void gemm_skinny_n_kernel(const GemmArgs
     }
   const int lrow = lane / LPR, lcol = (lane % LPR) * 4;
   const bool col_ok = lcol < g.K;
-  const bool fast_store = g.N == 16 && g.beta == 0.0f && !g.gate && (g.ldc % 4 == 0) &&
+  const bool fast_store = g.N == 16 && g.beta == 0.0f && !g.gate && !g.gate_bits && (g.ldc % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
   const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wid;
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -812,14 +823,15 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
-                     const gcnx_dropout *a_drop, void *ws, size_t ws_bytes, void *stream);
+                     const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
+                     int64_t ldbits, void *ws, size_t ws_bytes, void *stream);
 
 extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                              const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                              int64_t ldc, float alpha, float beta, int fuse_relu, void *ws,
                              size_t ws_bytes, void *stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr,
-                   0, 1.0f, nullptr, ws, ws_bytes, stream);
+                   0, 1.0f, nullptr, nullptr, nullptr, 0, ws, ws_bytes, stream);
 }
 
 // Shape part of the MFMA dispatch rules (pointer alignment is checked at call time).
@@ -840,7 +852,18 @@ extern "C" int gcnx_gemm_dropout_a_f32(int trans_a, int trans_b, int64_t M, int6
                                        void *stream) {
   GCNX_REQUIRE(a_dropout, GCNX_ERR_INVALID_ARG, "gemm_dropout_a: null descriptor");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f,
-                   a_dropout, ws, ws_bytes, stream);
+                   a_dropout, nullptr, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, int64_t K,
+                                            const float *A, int64_t lda,
+                                            const gcnx_dropout *a_dropout, const int32_t *a_row_ids,
+                                            const float *B, int64_t ldb, float *C, int64_t ldc,
+                                            float alpha, float beta, void *ws, size_t ws_bytes,
+                                            void *stream) {
+  GCNX_REQUIRE(a_dropout && a_row_ids, GCNX_ERR_INVALID_ARG, "gemm_dropout_a_rows: null argument");
+  return gemm_impl(0, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f,
+                   a_dropout, a_row_ids, nullptr, 0, ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
@@ -850,13 +873,24 @@ extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t 
                                    size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(gate && ldgate >= N, GCNX_ERR_INVALID_ARG, "gemm_gated: bad gate");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, gate, ldgate,
-                   gate_scale, nullptr, ws, ws_bytes, stream);
+                   gate_scale, nullptr, nullptr, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_gemm_bitgated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                      const float *A, int64_t lda, const float *B, int64_t ldb,
+                                      float *C, int64_t ldc, float alpha, float beta,
+                                      const uint32_t *gate_bits, int64_t ld_words, float gate_scale,
+                                      void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(gate_bits && ld_words * 32 >= N, GCNX_ERR_INVALID_ARG, "gemm_bitgated: bad gate");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0,
+                   gate_scale, nullptr, nullptr, gate_bits, ld_words, ws, ws_bytes, stream);
 }
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
-                     const gcnx_dropout *a_drop, void *ws, size_t ws_bytes, void *stream) {
+                     const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
+                     int64_t ldbits, void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
   if (M == 0 || N == 0) return GCNX_OK;
   GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
@@ -871,6 +905,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   g.partial = nullptr; g.splits = 1; g.k_per_split = K > 0 ? K : 1;
   g.gate = gate; g.ldgate = ldgate; g.gate_scale = gate_scale;
   g.adrop_keep = 1.0f; g.adrop_seed = 0; g.adrop_offset = 0; g.adrop_ld = 0;
+  g.adrop_rows = nullptr; g.gate_bits = gate_bits; g.ldbits = ldbits;
   const bool want_adrop = a_drop && a_drop->keep < 1.0f;
   if (want_adrop) {
     GCNX_REQUIRE(a_drop->keep > 0.0f && a_drop->offset % 4 == 0 && a_drop->ld % 4 == 0 &&
@@ -878,6 +913,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                  GCNX_ERR_INVALID_ARG, "gemm: A-dropout needs keep > 0, offset and ld multiples of 4, col0 = 0");
     g.adrop_keep = a_drop->keep; g.adrop_seed = a_drop->seed; g.adrop_offset = a_drop->offset;
     g.adrop_ld = a_drop->ld;
+    GCNX_REQUIRE(!a_rows || !trans_a, GCNX_ERR_UNSUPPORTED, "gemm: row ids for the A-dropout need a plain A");
+    g.adrop_rows = a_rows;
   }
 
   // tiny inner dimension, wide output: the streaming kernel
@@ -893,7 +930,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     GCNX_CHECK_LAUNCH();
     return GCNX_OK;
   }
-  if (small_k) {
+  if (small_k && !gate_bits) {
     int64_t blocks = ceil_div(ceil_div(M, 2), kWavesPerBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));

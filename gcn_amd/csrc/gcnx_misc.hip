@@ -244,6 +244,29 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float *__restri
   }
 }
 
+// One wavefront per 64 output words: word (i, w) collects the signs of
+// x[row(i)][32w .. 32w+31] (bit j set <=> element > 0) with a wavefront ballot
+// per 64 columns, so reads are coalesced and every lane writes at most once.
+__global__ __launch_bounds__(kBlock) void pack_sign_bits_kernel(int64_t n_rows,
+                                                               const int32_t *__restrict__ row_idx,
+                                                               const float *__restrict__ x, int64_t ldx,
+                                                               int32_t width, uint32_t *__restrict__ bits,
+                                                               int64_t ldw) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t i = wave; i < n_rows; i += nwaves) {
+    const int64_t r = row_idx ? (int64_t)row_idx[i] : i;
+    for (int c0 = 0; c0 < width; c0 += kWave) {
+      const int c = c0 + lane;
+      const bool on = c < width && x[r * ldx + c] > 0.0f;
+      const uint64_t m = __ballot(on);
+      if (lane == 0) bits[i * ldw + (c0 >> 5)] = (uint32_t)m;
+      if (lane == 32 && c0 + 32 < width) bits[i * ldw + (c0 >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+  }
+}
+
 __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
 // byte k of the mask = 1 iff uniform(seed, offset + k) < keep; four consecutive
@@ -496,6 +519,21 @@ extern "C" int gcnx_adam_step_dev_f32(int64_t n, float *w, const float *grad, fl
   if (n == 0) return GCNX_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, as_stream(stream), n, w,
                      grad, m, v, lr, beta1, beta2, eps, weight_decay, t_dev);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_pack_sign_bits_f32(int64_t n_rows, const int32_t *row_idx, const float *x,
+                                       int64_t ldx, int32_t width, uint32_t *bits, int64_t ld_words,
+                                       void *stream) {
+  GCNX_REQUIRE(n_rows >= 0 && width >= 0 && ldx >= width && ld_words * 32 >= width,
+               GCNX_ERR_INVALID_ARG, "pack_sign_bits: bad shape");
+  if (n_rows == 0 || width == 0) return GCNX_OK;
+  GCNX_REQUIRE(x && bits, GCNX_ERR_INVALID_ARG, "pack_sign_bits: null argument");
+  int64_t blocks = ceil_div(n_rows, kWavesPerBlock);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(pack_sign_bits_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
+                     n_rows, row_idx, x, ldx, width, bits, ld_words);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

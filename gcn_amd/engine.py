@@ -16,8 +16,15 @@ every activation; before each SpMM the rows of the dense operand that the block
 references on other ranks (the halo, gcn_amd/halo.py) are fetched with a
 variable-size all-to-all (RCCL over xGMI via torch.distributed), issued in column
 slabs on the communication stream so that the SpMM of slab s overlaps the
-transfer of slab s+1.  Weight gradients and the loss are all-reduced; Adam runs
-replicated.  Dropout masks are a pure function of (seed, step, global element
+transfer of slab s+1.  For the two hidden-width products the halo rows are not
+sent at all but recomputed by the GPU that needs them (``halo_mode``): the
+features are constant, so each GPU keeps a copy of the remote feature rows it
+references and forms dropout(X) W1 for them itself; in the backward pass only
+the class-width rows of dP2 and the sign bits of the remote rows of H' travel
+(96 bytes per row instead of 1 KiB at hidden 256) and the gated product
+dP2 W2^T is formed locally.  Same operations in the same order on the same
+numbers, so the result does not depend on the mode.  Weight gradients and the
+loss are all-reduced; Adam runs replicated.  Dropout masks are a pure function of (seed, step, global element
 index), so a run gives the same numbers for any GPU count.
 """
 import math
@@ -31,13 +38,16 @@ class FullBatchGCN(object):
     def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
-                 kernels=None, keep_masks=False):
+                 kernels=None, keep_masks=False, halo_mode="auto"):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
         ``w1`` [F, hidden], ``w2`` [hidden, n_class]: initial weights (device
         tensors, identical on every rank).  ``mask_total``: number of labelled
-        rows over all ranks."""
+        rows over all ranks.  ``halo_mode``: "exchange" sends the halo rows of
+        every dense operand; "recompute" forms the hidden-width halo rows
+        locally (see the module text); "auto" picks "recompute" when the
+        kernels serve it for these shapes."""
         self.k = kernels if kernels is not None else _hip_ops
         self.a = a_local
         self.at = a_bwd_local if a_bwd_local is not None else a_local
@@ -93,8 +103,52 @@ class FullBatchGCN(object):
             n_send = max(self.plan.n_send, self.plan_bwd.n_send, 1)
             self.halobuf = [e(n_halo * self.slab), e(n_halo * self.slab)]
             self.sendbuf = [e(n_send * self.slab), e(n_send * self.slab)]
+            self.recompute = self._setup_recompute(halo_mode)
         else:
             self.slab = None
+            self.recompute = False
+
+    # --------------------------------------------------- halo rows by recompute
+    def _setup_recompute(self, halo_mode):
+        if halo_mode not in ("auto", "exchange", "recompute"):
+            raise ValueError("halo_mode must be auto, exchange or recompute")
+        k, plan = self.k, self.plan
+        ok = (halo_mode != "exchange" and self.plan_bwd is plan and self.h % 32 == 0 and
+              hasattr(k, "pack_sign_bits") and (self.keep >= 1.0 or self.fuse_x_dropout))
+        if ok and self.keep < 1.0 and plan.n_halo:
+            sup = getattr(k, "gemm_supports_a_dropout", None)
+            ok = sup is not None and bool(sup(False, plan.n_halo, self.h, self.f))
+        if not ok:
+            if halo_mode == "recompute":
+                raise ValueError("halo_mode='recompute' is not served for this configuration")
+            return False
+        e = lambda *s, **kw: torch.empty(s, dtype=kw.get("dtype", torch.float32), device=self.dev)
+        nh, ns = max(plan.n_halo, 1), max(plan.n_send, 1)
+        # resident copy of the remote feature rows this block references (fetched once)
+        self.x_halo = e(nh, self.f)
+        self._exchange_rows(plan, self.x, self.x_halo)
+        self.wide_halo = e(nh, self.h)               # halo rows of P1, later of d(A P1)
+        words = self.h // 32
+        self.hbits_send = e(ns, words, dtype=torch.int32)
+        self.hbits_halo = e(nh, words, dtype=torch.int32)
+        self.dp2_send, self.dp2_halo = e(ns, self.c), e(nh, self.c)
+        self._bits_work = None
+        return True
+
+    def _exchange_rows(self, plan, src, dst):
+        """dst[i, :] = row plan.need[i] of the global matrix whose local rows are
+        ``src`` (blocking, in column slabs through the slab buffers)."""
+        w = src.shape[1]
+        slab = min(self.slab, w)
+        for c0 in range(0, w, slab):
+            nc = min(slab, w - c0)
+            sb = self.sendbuf[0][:plan.n_send * nc].view(plan.n_send, nc)
+            hb = self.halobuf[0][:plan.n_halo * nc].view(plan.n_halo, nc)
+            if plan.n_send:
+                self.k.gather_rows(src[:, c0:c0 + nc], plan.send_idx, sb)
+            self._all_to_all(hb, sb, plan.recv_counts, plan.send_counts)
+            if plan.n_halo:
+                dst[:plan.n_halo, c0:c0 + nc].copy_(hb)
 
     # ------------------------------------------------------------ collectives
     def _aggregate(self, which, src, dst, relu, dropout=None):
@@ -155,8 +209,8 @@ class FullBatchGCN(object):
         k = self.k
         keep = self.keep if train else 1.0
         xdrop = None
+        off = self.step_no * (1 << 44)
         if keep < 1.0:
-            off = self.step_no * (1 << 44)
             xkey = (keep, self.seed * 2 + 1, off + self.row_begin * self.f)
             if self.fuse_x_dropout:
                 xin, xdrop = self.x, xkey
@@ -173,7 +227,28 @@ class FullBatchGCN(object):
         # H' = dropout(relu(A P1)) straight out of the SpMM epilogue; H itself is
         # never stored (the backward pass only needs the sign pattern of H')
         drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h) if keep < 1.0 else None
-        self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop)
+        if self.recompute:
+            plan = self.plan
+            nh = plan.n_halo
+            if nh:
+                # P1 of the halo rows from the resident remote feature rows; their
+                # dropout mask is the one their owner draws (global element index)
+                if keep < 1.0:
+                    k.gemm(self.x_halo[:nh], self.w1, out=self.wide_halo[:nh],
+                           a_dropout=(keep, self.seed * 2 + 1, off), a_dropout_rows=plan.need)
+                else:
+                    k.gemm(self.x_halo[:nh], self.w1, out=self.wide_halo[:nh])
+            k.spmm(plan.csr, self.p1, out=self.hd, relu=True, b2=self.wide_halo[:nh] if nh else None,
+                   dropout=None if drop is None else drop + (self.h, 0))
+            if train:
+                # the backward pass gates the halo rows of d(A P1) with the sign of
+                # the owners' H': 1 bit per element, sent while layer 2 runs
+                if plan.n_send:
+                    k.pack_sign_bits(self.hd, rows=plan.send_idx, out=self.hbits_send[:plan.n_send])
+                self._bits_work = self._all_to_all_start(self.hbits_halo[:nh], self.hbits_send[:plan.n_send],
+                                                         plan.recv_counts, plan.send_counts)
+        else:
+            self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop)
         hin = self.hd
         k.gemm(hin, self.w2, out=self.p2)
         self._aggregate("fwd", self.p2, self.z, relu=False)
@@ -194,11 +269,32 @@ class FullBatchGCN(object):
         keep = self.keep
         # layer 2
         self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
+        dp2_work = None
+        if self.recompute:
+            plan = self.plan
+            if plan.n_send:
+                k.gather_rows(self.dp2, plan.send_idx, self.dp2_send[:plan.n_send])
+            dp2_work = self._all_to_all_start(self.dp2_halo[:plan.n_halo], self.dp2_send[:plan.n_send],
+                                              plan.recv_counts, plan.send_counts)
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
         k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
         # layer 1
-        self._aggregate("bwd", self.p1, self.hb, relu=False)             # A^T dH -> dP1
+        if self.recompute:
+            plan = self.plan
+            nh = plan.n_halo
+            for work in (dp2_work, self._bits_work):
+                if work is not None:
+                    work.wait()
+            self._bits_work = None
+            if nh:
+                # the same gated product for the halo rows, from the received rows
+                # of dP2 and the received sign bits of the owners' H'
+                k.gemm(self.dp2_halo[:nh], self.w2, trans_b=True, out=self.wide_halo[:nh],
+                       gate_bits=self.hbits_halo[:nh], gate_scale=1.0 / keep)
+            k.spmm(plan.csr, self.p1, out=self.hb, b2=self.wide_halo[:nh] if nh else None)
+        else:
+            self._aggregate("bwd", self.p1, self.hb, relu=False)         # A^T dH -> dP1
         if xdrop is not None:
             k.gemm(xin, self.hb, trans_a=True, out=self.g1, a_dropout=xdrop)  # X'^T dP1, X' regenerated
         else:

@@ -50,6 +50,7 @@ class HaloPlan(object):
         variable-size all-to-all along dim 0 (counts are Python lists)."""
         self.world, self.rank, self.n_loc = world, rank, int(n_loc)
         self.csr, need = plan_fn(a_local, row_begin, n_loc)
+        self.need = need                     # global ids of the halo rows, ascending (int32)
         dev = need.device
         self.n_halo = int(need.numel())
         # need[] is sorted by global id, hence grouped by owner

@@ -136,14 +136,18 @@ def spmm_add_autograd(a, b, c, alpha=1.0, relu=False):
 
 # ------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
-         gate_scale=1.0, a_dropout=None):
+         gate_scale=1.0, a_dropout=None, a_dropout_rows=None, gate_bits=None):
     """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
     ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35).  With ``gate``
     (same shape as out) the epilogue is ``gate > 0 ? out * gate_scale : 0``: the
     backward of relu + dropout fused into the product that feeds it.
     ``a_dropout=(keep, seed, offset)`` applies dropout to ``a`` (as stored,
     row-major with its own row length) while it is read, so dropout(a) is never
-    written (MFMA shapes only)."""
+    written (MFMA shapes only); with ``a_dropout_rows`` (int32, one per row of a
+    plain ``a``) row i draws the mask of row ``a_dropout_rows[i]`` (``a`` holds a
+    gathered subset of the rows the mask is defined on).  ``gate_bits`` (uint32 /
+    int32 [M, ceil(N/32)]) is the gate as one bit per element
+    (:func:`pack_sign_bits`)."""
     lib = _lib.load()
     _check_dense(a, "a")
     _check_dense(b, "b")
@@ -165,12 +169,36 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
         if a_dropout is not None and a_dropout[0] < 1.0:
             if gate is not None or relu or not a.is_contiguous():
                 raise ValueError("a_dropout excludes gate / relu and needs a contiguous a")
+            if gate_bits is not None:
+                raise ValueError("a_dropout excludes gate_bits")
             keep, seed, offset = a_dropout
             d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), a.shape[1], 0)
-            _lib.check(lib.gcnx_gemm_dropout_a_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
-                                                   a.stride(0), C.byref(d), _ptr(b), b.stride(0),
-                                                   _ptr(out), out.stride(0), float(alpha), float(beta),
-                                                   _ptr(ws), ws.numel(), _stream()))
+            if a_dropout_rows is not None:
+                r = a_dropout_rows
+                if trans_a or r.dtype != torch.int32 or r.numel() != M or not r.is_contiguous() or \
+                        r.device != a.device:
+                    raise ValueError("a_dropout_rows: one contiguous int32 per row of a plain a")
+                _lib.check(lib.gcnx_gemm_dropout_a_rows_f32(int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                                            C.byref(d), _ptr(r), _ptr(b), b.stride(0),
+                                                            _ptr(out), out.stride(0), float(alpha),
+                                                            float(beta), _ptr(ws), ws.numel(), _stream()))
+            else:
+                _lib.check(lib.gcnx_gemm_dropout_a_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
+                                                       a.stride(0), C.byref(d), _ptr(b), b.stride(0),
+                                                       _ptr(out), out.stride(0), float(alpha), float(beta),
+                                                       _ptr(ws), ws.numel(), _stream()))
+        elif gate_bits is not None:
+            gb = gate_bits
+            if gate is not None or relu:
+                raise ValueError("gate_bits excludes gate / relu")
+            if gb.dtype not in (torch.int32, torch.uint32) or gb.dim() != 2 or gb.shape[0] != M or \
+                    gb.shape[1] * 32 < N or gb.stride(1) != 1 or gb.device != a.device:
+                raise ValueError("gate_bits must be a 32-bit integer tensor [M, ceil(N/32)]")
+            _lib.check(lib.gcnx_gemm_bitgated_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
+                                                  a.stride(0), _ptr(b), b.stride(0), _ptr(out),
+                                                  out.stride(0), float(alpha), float(beta), _ptr(gb),
+                                                  gb.stride(0), float(gate_scale), _ptr(ws),
+                                                  ws.numel(), _stream()))
         elif gate is not None:
             _check_dense(gate, "gate")
             if tuple(gate.shape) != (M, N) or relu:
@@ -184,6 +212,26 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
             _lib.check(lib.gcnx_gemm_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
                                          _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
                                          float(beta), 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def pack_sign_bits(x, rows=None, out=None):
+    """int32 [n, ceil(W/32)]: bit (c % 32) of word (i, c // 32) is set iff
+    ``x[rows[i] if rows is not None else i, c] > 0``."""
+    lib = _lib.load()
+    _check_dense(x, "x")
+    n = int(rows.numel()) if rows is not None else x.shape[0]
+    width = x.shape[1]
+    words = (width + 31) // 32
+    if rows is not None and (rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != x.device):
+        raise ValueError("rows must be a contiguous int32 tensor on the device of x")
+    if out is None:
+        out = torch.empty((n, words), dtype=torch.int32, device=x.device)
+    elif out.dtype != torch.int32 or tuple(out.shape) != (n, words) or out.stride(1) != 1:
+        raise ValueError("out must be int32 [n, ceil(W/32)]")
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gcnx_pack_sign_bits_f32(n, _ptr(rows) if rows is not None else None, _ptr(x),
+                                               x.stride(0), width, _ptr(out), out.stride(0), _stream()))
     return out
 
 

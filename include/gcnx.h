@@ -240,6 +240,35 @@ int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t 
                         const float *gate, int64_t ldgate, float gate_scale,
                         void *ws, size_t ws_bytes, void *stream);
 
+/* The gate as one bit per element: bit (n % 32) of gate_bits[m * ld_words +
+ * n / 32] set <=> keep.  Used by the row-partitioned engine for the halo rows
+ * of d(A P1): only the sign pattern of the remote rows of H' travels (32 bytes
+ * per 256-wide row instead of 1 KiB), the gated product is recomputed locally
+ * from the remote rows of dP2.  No counterpart in the reference (single process). */
+int gcnx_gemm_bitgated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                           const float *A, int64_t lda, const float *B, int64_t ldb,
+                           float *C, int64_t ldc, float alpha, float beta,
+                           const uint32_t *gate_bits, int64_t ld_words,
+                           float gate_scale, void *ws, size_t ws_bytes, void *stream);
+
+/* bits[i * ld_words + w] = sign pattern (element > 0) of x[row(i)][32w .. 32w+31],
+ * row(i) = row_idx ? row_idx[i] : i; columns beyond width read as 0. */
+int gcnx_pack_sign_bits_f32(int64_t n_rows, const int32_t *row_idx, const float *x,
+                            int64_t ldx, int32_t width, uint32_t *bits,
+                            int64_t ld_words, void *stream);
+
+/* gcnx_gemm_dropout_a_f32 for a plain (not transposed) A that holds a gathered
+ * subset of the rows the mask is defined on: row i of A draws the mask of row
+ * a_row_ids[i], i.e. element (i, c) has index a_dropout->offset + a_row_ids[i] *
+ * a_dropout->ld + c.  Lets a GPU recompute dropout(X) W for the remote rows of
+ * X it holds a copy of (the features are constant) instead of receiving them. */
+int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, int64_t K,
+                                 const float *A, int64_t lda,
+                                 const gcnx_dropout *a_dropout,
+                                 const int32_t *a_row_ids, const float *B,
+                                 int64_t ldb, float *C, int64_t ldc, float alpha,
+                                 float beta, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- glue kernels of one training step ------------------------------------ */
 
 /* replaces: masked_softmax_cross_entropy + masked_accuracy, gcn/metrics.py:4-20.

@@ -105,8 +105,40 @@ class OracleKernels(object):
         out.copy_(t)
         return out
 
-    def gemm(self, a, b, trans_a=False, trans_b=False, out=None, gate=None, gate_scale=1.0, **kw):
-        r = self.torch.from_numpy(self.o.gemm(a.contiguous().numpy(), b.contiguous().numpy(), trans_a, trans_b))
+    def gemm_supports_a_dropout(self, trans_a, M, N, K):
+        return True
+
+    def pack_sign_bits(self, x, rows=None, out=None):
+        v = x.numpy() if rows is None else x.numpy()[rows.numpy().astype(np.int64)]
+        n, w = v.shape
+        words = (w + 31) // 32
+        on = np.zeros((n, words * 32), dtype=np.uint64)
+        on[:, :w] = v > 0
+        packed = (on.reshape(n, words, 32) << np.arange(32, dtype=np.uint64)).sum(axis=2)
+        t = self.torch.from_numpy(packed.astype(np.uint32).view(np.int32))
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    def gemm(self, a, b, trans_a=False, trans_b=False, out=None, gate=None, gate_scale=1.0, a_dropout=None,
+             a_dropout_rows=None, gate_bits=None, **kw):
+        an = a.contiguous().numpy()
+        if a_dropout is not None and a_dropout[0] < 1.0:
+            keep, seed, offset = a_dropout
+            rows = np.arange(an.shape[0], dtype=np.uint64) if a_dropout_rows is None else \
+                a_dropout_rows.numpy().astype(np.uint64)
+            idx = np.uint64(offset) + rows[:, None] * np.uint64(an.shape[1]) + \
+                np.arange(an.shape[1], dtype=np.uint64)[None, :]
+            m = self.o.bernoulli_mask_at(idx, keep, seed)
+            an = np.where(m != 0, an * np.float32(1.0 / keep), np.float32(0)).astype(np.float32)
+        r = self.torch.from_numpy(self.o.gemm(an, b.contiguous().numpy(), trans_a, trans_b))
+        if gate_bits is not None:
+            words = gate_bits.numpy().view(np.uint32)
+            cols = np.arange(r.shape[1])
+            on = (words[:, cols // 32] >> (cols % 32).astype(np.uint32)) & 1
+            r = self.torch.where(self.torch.from_numpy(on.astype(np.bool_)), r * gate_scale,
+                                 self.torch.zeros_like(r))
         if gate is not None:
             r = self.torch.where(gate > 0, r * gate_scale, self.torch.zeros_like(r))
         if out is None:

@@ -33,11 +33,11 @@ def _problem(scale=7, f=12, hidden=16, classes=5):
     return n, a_hat, x, w1, w2, labels, lmask, hidden, classes
 
 
-def _run(rank, world, port, slab, out_dir):
+def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem()
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(hidden=hidden)
     n_loc = n // world
     rb, re_ = rank * n_loc, (rank + 1) * n_loc
     T = torch.from_numpy
@@ -45,7 +45,9 @@ def _run(rank, world, port, slab, out_dir):
         CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
         int(lmask.sum()), hidden, classes, T(w1), T(w2), row_begin=rb, n_global=n, seed=5,
         group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank, slab_cols=slab,
-        kernels=OracleKernels())
+        kernels=OracleKernels(), halo_mode=halo_mode)
+    if world > 1:
+        assert eng.recompute == (halo_mode == "recompute")
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
     ev = eng.evaluate().numpy().copy()
     np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), outs=np.stack(outs), ev=ev,
@@ -63,11 +65,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,slab", [(2, 16), (2, 8), (4, 4)])
-def test_ranks_match_one_rank(tmp_path, world, slab):
+@pytest.mark.parametrize("world,slab,halo_mode,hidden", [
+    (2, 16, "exchange", 16), (2, 8, "exchange", 16), (4, 4, "exchange", 16),
+    # halo rows of the hidden-width products recomputed by the GPU that needs them
+    (2, 16, "recompute", 32), (4, 8, "recompute", 64)])
+def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden):
     out = str(tmp_path)
-    _run(0, 1, 0, None, out)
-    mp.spawn(_run, args=(world, _free_port(), slab, out), nprocs=world, join=True)
+    _run(0, 1, 0, None, out, "auto", hidden)
+    mp.spawn(_run, args=(world, _free_port(), slab, out, halo_mode, hidden), nprocs=world, join=True)
     one = np.load(os.path.join(out, "w1_r0.npz"))
     r0 = np.load(os.path.join(out, "w%d_r0.npz" % world))
     r1 = np.load(os.path.join(out, "w%d_r1.npz" % world))

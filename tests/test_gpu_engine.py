@@ -144,7 +144,8 @@ def test_spmm_properties_at_scale(env, scale):
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)
 
 
-def test_bench_two_ranks_match_one_rank_on_one_gpu():
+@pytest.mark.parametrize("halo_mode,features,hidden", [("exchange", 32, 64), ("recompute", 128, 128)])
+def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden):
     """bench.py end to end with 2 ranks sharing the one GPU (gloo rehearsal
     backend, host-staged all-gather; the HIP kernels, the row-range graph
     build, the slabbed gather and the all-reduces are the real ones) against
@@ -154,19 +155,19 @@ def test_bench_two_ranks_match_one_rank_on_one_gpu():
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    common = ["--scale", "14", "--steps", "3", "--warmup", "0", "--cpu-rows", "0", "--hidden", "64",
-              "--features", "32"]
+    common = ["--scale", "14", "--steps", "3", "--warmup", "0", "--cpu-rows", "0", "--hidden", str(hidden),
+              "--features", str(features)]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
                          capture_output=True, text=True, timeout=200, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--backend", "gloo", "--slab-cols", "16"] + common,
+                          "--gpus", "2", "--backend", "gloo", "--slab-cols", "16", "--halo-mode", halo_mode] + common,
                          capture_output=True, text=True, timeout=200, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["config"]["nnz_a_hat"] == j2["config"]["nnz_a_hat"]
-    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak"
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["halo_mode"] == halo_mode
     assert abs(j1["final_xent"] - j2["final_xent"]) <= 1e-5 * abs(j1["final_xent"])
     assert abs(j1["final_train_acc"] - j2["final_train_acc"]) <= 1e-6

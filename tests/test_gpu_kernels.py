@@ -497,3 +497,57 @@ def test_device_step_counters(env):
         np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-8)
     with pytest.raises(ValueError):
         ops.adam_step(w, g, m, v, 0.01, torch.zeros(1, device=dev))
+
+
+@pytest.mark.parametrize("n,width", [(1, 32), (1000, 256), (777, 64), (513, 100)])
+def test_pack_sign_bits(env, n, width):
+    torch = env["torch"]
+    rng = np.random.RandomState(n + width)
+    x = rng.standard_normal((n, width)).astype(np.float32)
+    x[rng.random_sample(x.shape) < 0.1] = 0.0
+    xt = torch.from_numpy(x).to(env["dev"])
+    words = (width + 31) // 32
+
+    def expect(v):
+        on = np.zeros((v.shape[0], words * 32), dtype=np.uint64)
+        on[:, :width] = v > 0
+        return (on.reshape(v.shape[0], words, 32) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+
+    got = env["ops"].pack_sign_bits(xt).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, expect(x))
+    rows = rng.randint(0, n, size=max(1, n // 3)).astype(np.int32)
+    got = env["ops"].pack_sign_bits(xt, rows=torch.from_numpy(rows).to(env["dev"])).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, expect(x[rows]))
+
+
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 1, 5001, 128, 16), (0, 0, 700, 33, 20),
+                                         (0, 0, 4096, 256, 128), (0, 1, 2048, 64, 7)])
+def test_gemm_bit_gate_equals_float_gate(env, ta, tb, M, N, K):
+    """The gate read as one bit per element gives the bits of the float gate."""
+    torch = env["torch"]
+    rng = np.random.RandomState(M + K + 1)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    gate = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)
+    at, bt, gt = (torch.from_numpy(t).to(env["dev"]) for t in (a, b, gate))
+    ref = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb), gate=gt, gate_scale=2.0)
+    bits = env["ops"].pack_sign_bits(gt)
+    got = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb), gate_bits=bits, gate_scale=2.0)
+    assert torch.equal(ref, got)
+
+
+def test_gemm_dropout_on_gathered_rows(env):
+    """dropout(A) W for a gathered subset of the rows == the same rows of the
+    full product (each row draws the mask of its global row id)."""
+    torch = env["torch"]
+    rng = np.random.RandomState(11)
+    M, N, K = 6000, 256, 128
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(env["dev"])
+    b = torch.from_numpy(rng.standard_normal((K, N)).astype(np.float32)).to(env["dev"])
+    off = 9 * (1 << 44)
+    full = env["ops"].gemm(a, b, a_dropout=(0.5, 31, off))
+    rows = np.sort(rng.choice(M, size=2500, replace=False)).astype(np.int32)
+    rt = torch.from_numpy(rows).to(env["dev"])
+    sub = a[rt.long()].contiguous()
+    got = env["ops"].gemm(sub, b, a_dropout=(0.5, 31, off), a_dropout_rows=rt)
+    assert torch.equal(got, full[rt.long()])
