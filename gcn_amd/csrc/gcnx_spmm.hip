@@ -667,7 +667,10 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
     if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
     return GCNX_OK;
   }
-#define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, 4>), dim3(gx), dim3(kBlock), 0, st, k)
+#ifndef GCNX_SLOT_U
+#define GCNX_SLOT_U 4       // gather groups in flight per wavefront in the narrow kernel
+#endif
+#define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, GCNX_SLOT_U>), dim3(gx), dim3(kBlock), 0, st, k)
   if (lanes > 32) {
     gy = (unsigned)ceil_div(lanes, kWave);
     if (v4) hipLaunchKernelGGL((spmm_chunk_kernel<4, GCNX_WIDE_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
