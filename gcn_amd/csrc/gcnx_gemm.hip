@@ -50,6 +50,14 @@ struct GemmArgs {
   // gate_bits[m * ldbits + n / 32] set <=> keep)
   const uint32_t *gate_bits;
   int64_t ldbits;
+  // dropout on the output behind the activation (keep >= 1: off); element (m, n)
+  // has Philox index odrop_offset + m * odrop_ld + odrop_col0 + n
+  float odrop_keep;
+  uint64_t odrop_seed;
+  uint64_t odrop_offset;
+  int64_t odrop_ld;
+  int64_t odrop_col0;
+  int odrop_vec;   // the 16-byte epilogue of the MFMA kernel may be used
 };
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
@@ -166,6 +174,38 @@ typedef float __attribute__((ext_vector_type(16))) f16v;
 
 constexpr int MB = 128;
 
+// One 32 x 32 accumulator tile (MFMA C/D layout: col = lane & 31, row = (reg & 3)
+// + 8 * (reg >> 2) + 4 * (lane >> 5)) -> wavefront-private LDS -> four rows x
+// 16 bytes per lane -> alpha, relu, output dropout (one Philox block per 16
+// bytes) -> global.
+__device__ __forceinline__ void store_tile_relu_dropout(const GemmArgs &g, const f16v &acc, float *my,
+                                                        int pitch, int lane, int64_t row0, int64_t col0) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int rgi = 0; rgi < 16; ++rgi) my[((rgi & 3) + 8 * (rgi >> 2) + 4 * lk) * pitch + li] = acc[rgi];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const float inv = 1.0f / g.odrop_keep;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = p * kWave + lane;
+    const int r = idx >> 3, c4 = (idx & 7) * 4;
+    const int64_t gm = row0 + r;
+    const int64_t gn = col0 + c4;
+    if (gm < g.M && gn < g.N) {
+      f4v v = *reinterpret_cast<const f4v *>(my + r * pitch + c4) * g.alpha;
+      const uint64_t e0 = g.odrop_offset + (uint64_t)gm * (uint64_t)g.odrop_ld + (uint64_t)(g.odrop_col0 + gn);
+      const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, g.odrop_seed);
+      f4v o;
+      o.x = ((float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.x, 0.0f) : v.x) * inv : 0.0f;
+      o.y = ((float)(rnd.v[1] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.y, 0.0f) : v.y) * inv : 0.0f;
+      o.z = ((float)(rnd.v[2] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.z, 0.0f) : v.z) * inv : 0.0f;
+      o.w = ((float)(rnd.v[3] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.w, 0.0f) : v.w) * inv : 0.0f;
+      *reinterpret_cast<f4v *>(g.C + gm * g.ldc + gn) = o;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // BN = 128 / 256: wavefront w owns rows [32w, 32w+32) and all BN columns (four
 // or eight accumulator tiles); 256 is used when N allows it, so that A is
 // streamed (and its fused dropout regenerated) once per 256 output columns.  BN = 32: the class-dimension / skinny case (N <= 32,
@@ -182,8 +222,14 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
   // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
   // stride-17 words (conflict free), lanes 32..63 the next k.
   constexpr int NT = BN / 32;
-  __shared__ float As[MB * (KB + 1)];
-  __shared__ float Bs[KB * BN];
+  // after the K loop the same memory holds one 32 x 32 output tile per wavefront
+  // (36-word pitch) for the 16-byte epilogue
+  constexpr int kTilePitch = 36;
+  constexpr int kStage = MB * (KB + 1) + KB * BN;
+  constexpr int kSmem = kStage > kWavesPerBlock * 32 * kTilePitch ? kStage : kWavesPerBlock * 32 * kTilePitch;
+  __shared__ __attribute__((aligned(16))) float smem[kSmem];
+  float *const As = smem;
+  float *const Bs = smem + MB * (KB + 1);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
@@ -290,6 +336,14 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
     __syncthreads();
   }
   // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  if (g.odrop_vec) {
+    // Output dropout: the tile is turned through LDS so that a lane holds four
+    // consecutive columns = one Philox block, and stores 16 bytes.
+    float *const my = smem + w * (32 * kTilePitch);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) store_tile_relu_dropout(g, acc[t], my, kTilePitch, lane, m0 + w * 32, n0 + t * 32);
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -828,14 +882,14 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
                      const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
-                     int64_t ldbits, void *ws, size_t ws_bytes, void *stream);
+                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream);
 
 extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                              const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                              int64_t ldc, float alpha, float beta, int fuse_relu, void *ws,
                              size_t ws_bytes, void *stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr,
-                   0, 1.0f, nullptr, nullptr, nullptr, 0, ws, ws_bytes, stream);
+                   0, 1.0f, nullptr, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream);
 }
 
 // Shape part of the MFMA dispatch rules (pointer alignment is checked at call time).
@@ -856,7 +910,7 @@ extern "C" int gcnx_gemm_dropout_a_f32(int trans_a, int trans_b, int64_t M, int6
                                        void *stream) {
   GCNX_REQUIRE(a_dropout, GCNX_ERR_INVALID_ARG, "gemm_dropout_a: null descriptor");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f,
-                   a_dropout, nullptr, nullptr, 0, ws, ws_bytes, stream);
+                   a_dropout, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, int64_t K,
@@ -867,7 +921,7 @@ extern "C" int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, i
                                             void *stream) {
   GCNX_REQUIRE(a_dropout && a_row_ids, GCNX_ERR_INVALID_ARG, "gemm_dropout_a_rows: null argument");
   return gemm_impl(0, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f,
-                   a_dropout, a_row_ids, nullptr, 0, ws, ws_bytes, stream);
+                   a_dropout, a_row_ids, nullptr, 0, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
@@ -877,7 +931,22 @@ extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t 
                                    size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(gate && ldgate >= N, GCNX_ERR_INVALID_ARG, "gemm_gated: bad gate");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, gate, ldgate,
-                   gate_scale, nullptr, nullptr, nullptr, 0, ws, ws_bytes, stream);
+                   gate_scale, nullptr, nullptr, nullptr, 0, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_gemm_relu_dropout_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                          const float *A, int64_t lda, const float *B, int64_t ldb,
+                                          float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
+                                          const gcnx_dropout *out_dropout, void *ws, size_t ws_bytes,
+                                          void *stream) {
+  GCNX_REQUIRE(out_dropout, GCNX_ERR_INVALID_ARG, "gemm_relu_dropout: null descriptor");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr, 0,
+                   1.0f, nullptr, nullptr, nullptr, 0, out_dropout, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_gemm_relu_dropout_supported(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
+  (void)trans_b;
+  return (!trans_a && nn_mfma_shape(M, N, K) && N % 4 == 0) ? 1 : 0;
 }
 
 extern "C" int gcnx_gemm_bitgated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
@@ -887,14 +956,14 @@ extern "C" int gcnx_gemm_bitgated_f32(int trans_a, int trans_b, int64_t M, int64
                                       void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(gate_bits && ld_words * 32 >= N, GCNX_ERR_INVALID_ARG, "gemm_bitgated: bad gate");
   return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0,
-                   gate_scale, nullptr, nullptr, gate_bits, ld_words, ws, ws_bytes, stream);
+                   gate_scale, nullptr, nullptr, gate_bits, ld_words, nullptr, ws, ws_bytes, stream);
 }
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
                      const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
-                     int64_t ldbits, void *ws, size_t ws_bytes, void *stream) {
+                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
   if (M == 0 || N == 0) return GCNX_OK;
   GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
@@ -910,6 +979,20 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   g.gate = gate; g.ldgate = ldgate; g.gate_scale = gate_scale;
   g.adrop_keep = 1.0f; g.adrop_seed = 0; g.adrop_offset = 0; g.adrop_ld = 0;
   g.adrop_rows = nullptr; g.gate_bits = gate_bits; g.ldbits = ldbits;
+  g.odrop_keep = 1.0f; g.odrop_seed = 0; g.odrop_offset = 0; g.odrop_ld = 0; g.odrop_col0 = 0; g.odrop_vec = 0;
+  const bool want_odrop = out_drop && out_drop->keep < 1.0f;
+  if (want_odrop) {
+    GCNX_REQUIRE(out_drop->keep > 0.0f && out_drop->ld >= N && out_drop->col0 >= 0, GCNX_ERR_INVALID_ARG,
+                 "gemm: bad output dropout descriptor");
+    g.odrop_keep = out_drop->keep; g.odrop_seed = out_drop->seed; g.odrop_offset = out_drop->offset;
+    g.odrop_ld = out_drop->ld; g.odrop_col0 = out_drop->col0;
+    g.odrop_vec = (beta == 0.0f && !gate && !gate_bits && N % 4 == 0 && ldc % 4 == 0 && aligned16(C) &&
+                   out_drop->offset % 4 == 0 && out_drop->ld % 4 == 0 && out_drop->col0 % 4 == 0) ? 1 : 0;
+  }
+  // output dropout lives in the 16-byte epilogue of the tall MFMA kernel only
+  GCNX_REQUIRE(!want_odrop || (g.odrop_vec && !trans_a && nn_mfma_shape(M, N, K) && (lda % 4 == 0) && aligned16(A) &&
+                               (trans_b || N <= 32 || ((ldb % 4 == 0) && aligned16(B)))),
+               GCNX_ERR_UNSUPPORTED, "gemm: output dropout is served for tall MFMA shapes with 16-byte aligned rows only");
   const bool want_adrop = a_drop && a_drop->keep < 1.0f;
   if (want_adrop) {
     GCNX_REQUIRE(a_drop->keep > 0.0f && a_drop->offset % 4 == 0 && a_drop->ld % 4 == 0 &&
@@ -925,7 +1008,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   const bool small_k = !trans_a && !want_adrop && K >= 1 && K <= 32 && N >= 64 && (N % 4 == 0) &&
                        M >= 1024 && (ldc % 4 == 0) && aligned16(C) &&
                        (!gate || ((ldgate % 4 == 0) && aligned16(gate)));
-  if (small_k && K <= 16 && N % 32 == 0) {
+  if (small_k && !want_odrop && K <= 16 && N % 32 == 0) {
     int64_t blocks = ceil_div(ceil_div(M, 32), kWavesPerBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));
@@ -934,7 +1017,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     GCNX_CHECK_LAUNCH();
     return GCNX_OK;
   }
-  if (small_k && !gate_bits) {
+  if (small_k && !gate_bits && !want_odrop) {
     int64_t blocks = ceil_div(ceil_div(M, 2), kWavesPerBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));
@@ -950,7 +1033,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   }
 
   // skinny output (the class dimension): stream A once, no LDS
-  const bool skinny_n = !trans_a && !trans_b && !want_adrop && N <= 16 && K >= 64 && K <= 256 &&
+  const bool skinny_n = !trans_a && !trans_b && !want_adrop && !want_odrop && N <= 16 && K >= 64 && K <= 256 &&
                         K % 16 == 0 && M >= 1024 && (lda % 4 == 0) && aligned16(A);
   if (skinny_n) {
     int64_t blocks = ceil_div(ceil_div(M, 16), kWavesPerBlock);

@@ -136,7 +136,7 @@ def spmm_add_autograd(a, b, c, alpha=1.0, relu=False):
 
 # ------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
-         gate_scale=1.0, a_dropout=None, a_dropout_rows=None, gate_bits=None):
+         gate_scale=1.0, a_dropout=None, a_dropout_rows=None, gate_bits=None, dropout=None):
     """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
     ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35).  With ``gate``
     (same shape as out) the epilogue is ``gate > 0 ? out * gate_scale : 0``: the
@@ -147,7 +147,8 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     plain ``a``) row i draws the mask of row ``a_dropout_rows[i]`` (``a`` holds a
     gathered subset of the rows the mask is defined on).  ``gate_bits`` (uint32 /
     int32 [M, ceil(N/32)]) is the gate as one bit per element
-    (:func:`pack_sign_bits`)."""
+    (:func:`pack_sign_bits`).  ``dropout=(keep, seed, offset, ld, col0)`` applies
+    dropout to the output behind the activation, as in :func:`spmm`."""
     lib = _lib.load()
     _check_dense(a, "a")
     _check_dense(b, "b")
@@ -166,7 +167,30 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     with torch.cuda.device(a.device):
         need = lib.gcnx_gemm_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         ws = WORKSPACE.get(need, a.device)
-        if a_dropout is not None and a_dropout[0] < 1.0:
+        if dropout is not None and dropout[0] < 1.0:
+            if gate is not None or gate_bits is not None or (a_dropout is not None and a_dropout[0] < 1.0) \
+                    or beta != 0.0:
+                raise ValueError("output dropout excludes gate, gate_bits, a_dropout and beta")
+            keep, seed, offset, ld, col0 = dropout
+            fused = bool(lib.gcnx_gemm_relu_dropout_supported(int(trans_a), int(trans_b), M, N, K)) and \
+                out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and \
+                a.data_ptr() % 16 == 0 and (trans_b or N <= 32 or (b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0)) \
+                and int(offset) % 4 == 0 and int(ld) % 4 == 0 and int(col0) % 4 == 0
+            if fused:
+                d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld), int(col0))
+                _lib.check(lib.gcnx_gemm_relu_dropout_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                                          _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                                          float(alpha), float(beta), 1 if relu else 0, C.byref(d),
+                                                          _ptr(ws), ws.numel(), _stream()))
+            else:
+                # shapes outside the tall MFMA kernel: the product, then the same mask in place
+                if int(ld) != N or int(col0) != 0 or not out.is_contiguous():
+                    raise ValueError("unfused output dropout needs ld == N, col0 == 0 and a contiguous out")
+                _lib.check(lib.gcnx_gemm_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                             _ptr(b), b.stride(0), _ptr(out), out.stride(0), float(alpha),
+                                             0.0, 1 if relu else 0, _ptr(ws), ws.numel(), _stream()))
+                dropout_philox(out.view(-1), keep, seed, offset, out=out.view(-1))
+        elif a_dropout is not None and a_dropout[0] < 1.0:
             if gate is not None or relu or not a.is_contiguous():
                 raise ValueError("a_dropout excludes gate / relu and needs a contiguous a")
             if gate_bits is not None:
@@ -233,6 +257,12 @@ def pack_sign_bits(x, rows=None, out=None):
         _lib.check(lib.gcnx_pack_sign_bits_f32(n, _ptr(rows) if rows is not None else None, _ptr(x),
                                                x.stride(0), width, _ptr(out), out.stride(0), _stream()))
     return out
+
+
+def gemm_supports_output_dropout(trans_a, M, N, K):
+    """Whether ``gemm(..., dropout=...)`` is fused into the product's epilogue
+    for this shape (otherwise the mask is applied by a second kernel)."""
+    return bool(_lib.load().gcnx_gemm_relu_dropout_supported(int(trans_a), 0, int(M), int(N), int(K)))
 
 
 def gemm_supports_a_dropout(trans_a, M, N, K):

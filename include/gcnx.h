@@ -240,6 +240,23 @@ int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t 
                         const float *gate, int64_t ldgate, float gate_scale,
                         void *ws, size_t ws_bytes, void *stream);
 
+/* The product followed by relu (fuse_relu != 0) and dropout on the output:
+ * element (m, n) is kept iff the Philox uniform at index out_dropout->offset +
+ * m * out_dropout->ld + out_dropout->col0 + n is < keep (the mask of
+ * gcnx_bernoulli_mask_u8 and of the SpMM epilogue), survivors scaled by 1/keep.
+ * replaces: act(.) of one layer followed by tf.nn.dropout at the head of the
+ * next (gcn/layers.py:226 then :210) when the layer ends in the dense product,
+ * i.e. when a caller evaluates (A_hat x) W instead of A_hat (x W).  Served by
+ * the tall MFMA kernel only (gcnx_gemm_relu_dropout_supported; rows of C and the
+ * descriptor's offset / ld / col0 multiples of 4, beta = 0); other shapes return
+ * GCNX_ERR_UNSUPPORTED and the caller applies gcnx_dropout_philox_f32 afterwards. */
+int gcnx_gemm_relu_dropout_supported(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+int gcnx_gemm_relu_dropout_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                               const float *A, int64_t lda, const float *B, int64_t ldb,
+                               float *C, int64_t ldc, float alpha, float beta,
+                               int fuse_relu, const gcnx_dropout *out_dropout,
+                               void *ws, size_t ws_bytes, void *stream);
+
 /* The gate as one bit per element: bit (n % 32) of gate_bits[m * ld_words +
  * n / 32] set <=> keep.  Used by the row-partitioned engine for the halo rows
  * of d(A P1): only the sign pattern of the remote rows of H' travels (32 bytes
