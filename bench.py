@@ -92,6 +92,8 @@ def main():
                     help="with --verbose: dump all Python stacks and exit after this many seconds")
     ap.add_argument("--halo-mode", default="auto", choices=["auto", "exchange", "recompute"],
                     help="several GPUs: send the hidden-width halo rows, or recompute them where they are needed")
+    ap.add_argument("--order", default="reference", choices=["reference", "aggregate_first"],
+                    help="first layer as A_hat (X' W1) like the reference (default) or as (A_hat X') W1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
                     "ranks sharing one GPU)")
     args = ap.parse_args()
@@ -188,7 +190,7 @@ def main():
 
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                                 row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
-                                slab_cols=args.slab_cols or None, halo_mode=args.halo_mode)
+                                slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -209,7 +211,8 @@ def main():
             return getattr(ops, name)
 
         def spmm(self, aa, b, **kw):
-            if Timed.armed and b.shape[1] == args.hidden and len(ev_used) < n_ev:
+            if Timed.armed and b.shape[1] == (args.hidden if args.order == "reference" else args.features) \
+                    and len(ev_used) < n_ev:
                 s, e = ev[len(ev_used)]
                 ops.profile_spmm_events(s, e)
                 out = real_spmm(aa, b, **kw)
@@ -261,7 +264,10 @@ def main():
                 "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
                 "halo_rows_rank0": (model.plan.n_halo if model.plan is not None else 0),
                 "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
-                "spmm_per_step": "2 x width %d + 2 x width %d" % (args.hidden, args.classes),
+                "order": args.order,
+                "spmm_per_step": ("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
+                                  if args.order == "reference" else
+                                  "1 x width %d + 2 x width %d" % (args.features, args.classes)),
             },
             "epoch_ms": dt / args.steps * 1e3,
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],

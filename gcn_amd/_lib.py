@@ -89,6 +89,7 @@ SIGNATURES = {
     "gcnx_counter_add_u64": (_int, [_p, _u64, _p]),
     "gcnx_philox_uniform_f32": (_int, [_i64, _f32, _f32, _u64, _u64, _p, _p]),
     "gcnx_dropout_philox_f32": (_int, [_i64, _p, _f32, _u64, _u64, _p, _p, _p]),
+    "gcnx_dropout_rows_philox_f32": (_int, [_i64, _i32, _p, _i64, _p, _f32, _u64, _u64, _p, _i64, _p]),
     "gcnx_relu_dropout_bwd_philox_f32": (_int, [_i64, _p, _p, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),
     "gcnx_adam_step_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),

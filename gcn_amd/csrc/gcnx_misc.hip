@@ -267,6 +267,43 @@ __global__ __launch_bounds__(kBlock) void pack_sign_bits_kernel(int64_t n_rows,
   }
 }
 
+// Dropout of gathered rows: out[i][c] = keep(offset + row_ids[i] * width + c) ?
+// x[i][c] * scale : 0, i.e. row i draws the mask of row row_ids[i] of the matrix
+// (row length `width`) the mask is defined on.  A thread handles 4 consecutive
+// columns (one Philox block) when vec_ok, else one element.
+__global__ __launch_bounds__(kBlock) void dropout_rows_philox_kernel(
+    int64_t n_rows, int32_t width, const float *__restrict__ x, int64_t ldx,
+    const int32_t *__restrict__ row_ids, float keep, float scale, uint64_t seed, uint64_t offset,
+    float *__restrict__ out, int64_t ldo, int vec_ok) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec_ok) {
+    const int w4 = width / 4;
+    const int64_t total = n_rows * (int64_t)w4;
+    for (int64_t t = tid; t < total; t += stride) {
+      const int64_t i = t / w4;
+      const int c = (int)(t % w4) * 4;
+      const uint64_t e = offset + (uint64_t)row_ids[i] * (uint64_t)width + (uint64_t)c;
+      const philox4 r = philox4x32_10(e >> 2, 0ull, seed);
+      const f4 v = *reinterpret_cast<const f4 *>(x + i * ldx + c);
+      f4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = ((float)(r.v[j] >> 8) * (1.0f / 16777216.0f) < keep) ? v[j] * scale : 0.0f;
+      *reinterpret_cast<f4 *>(out + i * ldo + c) = o;
+    }
+  } else {
+    const int64_t total = n_rows * (int64_t)width;
+    for (int64_t t = tid; t < total; t += stride) {
+      const int64_t i = t / width;
+      const int c = (int)(t % width);
+      const uint64_t e = offset + (uint64_t)row_ids[i] * (uint64_t)width + (uint64_t)c;
+      const philox4 r = philox4x32_10(e >> 2, 0ull, seed);
+      out[i * ldo + c] = ((float)(r.v[e & 3] >> 8) * (1.0f / 16777216.0f) < keep) ? x[i * ldx + c] * scale : 0.0f;
+    }
+  }
+}
+
 __global__ void counter_add_kernel(uint64_t *ctr, uint64_t inc) { *ctr += inc; }
 
 // byte k of the mask = 1 iff uniform(seed, offset + k) < keep; four consecutive
@@ -534,6 +571,22 @@ extern "C" int gcnx_pack_sign_bits_f32(int64_t n_rows, const int32_t *row_idx, c
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(pack_sign_bits_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
                      n_rows, row_idx, x, ldx, width, bits, ld_words);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_dropout_rows_philox_f32(int64_t n_rows, int32_t width, const float *x, int64_t ldx,
+                                            const int32_t *row_ids, float keep, uint64_t seed,
+                                            uint64_t offset, float *out, int64_t ldo, void *stream) {
+  GCNX_REQUIRE(n_rows >= 0 && width >= 0 && keep > 0.0f && ldx >= width && ldo >= width,
+               GCNX_ERR_INVALID_ARG, "dropout_rows_philox: bad argument");
+  if (n_rows == 0 || width == 0) return GCNX_OK;
+  GCNX_REQUIRE(x && out && row_ids, GCNX_ERR_INVALID_ARG, "dropout_rows_philox: null argument");
+  const int vec_ok = aligned16(x) && aligned16(out) && (offset % 4 == 0) && (width % 4 == 0) &&
+                     (ldx % 4 == 0) && (ldo % 4 == 0);
+  const int64_t work = vec_ok ? n_rows * (int64_t)(width / 4) : n_rows * (int64_t)width;
+  hipLaunchKernelGGL(dropout_rows_philox_kernel, dim3(stream_grid(work)), dim3(kBlock), 0, as_stream(stream),
+                     n_rows, width, x, ldx, row_ids, keep, 1.0f / keep, seed, offset, out, ldo, vec_ok);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

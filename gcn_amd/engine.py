@@ -24,7 +24,15 @@ the class-width rows of dP2 and the sign bits of the remote rows of H' travel
 (96 bytes per row instead of 1 KiB at hidden 256) and the gated product
 dP2 W2^T is formed locally.  Same operations in the same order on the same
 numbers, so the result does not depend on the mode.  Weight gradients and the
-loss are all-reduced; Adam runs replicated.  Dropout masks are a pure function of (seed, step, global element
+loss are all-reduced; Adam runs replicated.
+
+``order="aggregate_first"`` (opt-in) evaluates the first layer as
+(A_hat X') W1 instead of A_hat (X' W1) -- the same sum, associated the other
+way, so results agree with the reference order to fp32 rounding, not to the
+bit.  Because the features need no gradient, the weight gradient becomes
+(A_hat X')^T dZ1 with A_hat X' kept from the forward pass: the hidden-width
+backward SpMM disappears, and with several GPUs so does every hidden-width
+exchange (the remote feature rows are resident).  Dropout masks are a pure function of (seed, step, global element
 index), so a run gives the same numbers for any GPU count.
 """
 import math
@@ -38,7 +46,7 @@ class FullBatchGCN(object):
     def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
-                 kernels=None, keep_masks=False, halo_mode="auto"):
+                 kernels=None, keep_masks=False, halo_mode="auto", order="reference"):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -62,6 +70,10 @@ class FullBatchGCN(object):
         self.dev = x_local.device
         self.lr, self.wd, self.keep = lr, weight_decay, 1.0 - dropout
         self.seed = int(seed)
+        if order not in ("reference", "aggregate_first"):
+            raise ValueError("order must be 'reference' or 'aggregate_first'")
+        self.order = order
+        agg_first = order == "aggregate_first"
         self.group, self.world = group, int(world_size)
         self.step_no = 0
         self.keep_masks = keep_masks
@@ -75,11 +87,12 @@ class FullBatchGCN(object):
         # dropout(X) is regenerated inside the two products that read it when
         # their shapes are served by the MFMA kernels; otherwise it is stored
         sup = getattr(self.k, "gemm_supports_a_dropout", None)
-        self.fuse_x_dropout = bool(self.keep < 1.0 and not keep_masks and sup is not None and
+        self.fuse_x_dropout = bool(self.keep < 1.0 and not keep_masks and not agg_first and sup is not None and
                                    sup(False, nl, self.h, self.f) and sup(True, self.f, self.h, nl))
         self.xd = None if (self.fuse_x_dropout or self.keep >= 1.0) else e(nl, self.f)   # dropout(X)
         self.p1 = e(nl, self.h)        # X' W1; later the gradient wrt A P1
-        self.hb = e(nl, self.h)        # A^T dH (gradient wrt P1)
+        self.hb = None if agg_first else e(nl, self.h)        # A^T dH (gradient wrt P1)
+        self.ax = e(nl, self.f) if agg_first else None          # A_hat X' (aggregate-first order)
         self.hd = e(nl, self.h)        # H' = dropout(relu(A P1))
         self.p2 = e(nl, self.c)
         self.z = e(nl, self.c)
@@ -103,7 +116,14 @@ class FullBatchGCN(object):
             n_send = max(self.plan.n_send, self.plan_bwd.n_send, 1)
             self.halobuf = [e(n_halo * self.slab), e(n_halo * self.slab)]
             self.sendbuf = [e(n_send * self.slab), e(n_send * self.slab)]
-            self.recompute = self._setup_recompute(halo_mode)
+            if agg_first:
+                self.recompute = False
+                nh = max(self.plan.n_halo, 1)
+                self.x_halo = e(nh, self.f)                     # resident remote feature rows
+                self._exchange_rows(self.plan, self.x, self.x_halo)
+                self.xd_halo = e(nh, self.f) if self.keep < 1.0 else None
+            else:
+                self.recompute = self._setup_recompute(halo_mode)
         else:
             self.slab = None
             self.recompute = False
@@ -205,7 +225,34 @@ class FullBatchGCN(object):
         return t
 
     # ------------------------------------------------------------------- step
+    def _forward_aggregate_first(self, train):
+        """H' = dropout(relu((A_hat X') W1)); layer 2 as in the reference order."""
+        k = self.k
+        keep = self.keep if train else 1.0
+        off = self.step_no * (1 << 44)
+        nh = self.plan.n_halo if self.world > 1 else 0
+        xin, xh = self.x, (self.x_halo[:nh] if nh else None)
+        if keep < 1.0:
+            k.dropout_philox(self.x.view(-1), keep, self.seed * 2 + 1, off + self.row_begin * self.f,
+                             out=self.xd.view(-1), mask_out=self.mask1)
+            xin = self.xd
+            if nh:
+                k.dropout_rows_philox(self.x_halo[:nh], self.plan.need, keep, self.seed * 2 + 1, off,
+                                      out=self.xd_halo[:nh])
+                xh = self.xd_halo[:nh]
+        if self.world == 1:
+            k.spmm(self.a, xin, out=self.ax)
+        else:
+            k.spmm(self.plan.csr, xin, out=self.ax, b2=xh)
+        drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h, self.h, 0) if keep < 1.0 else None
+        k.gemm(self.ax, self.w1, out=self.hd, relu=True, dropout=drop)
+        k.gemm(self.hd, self.w2, out=self.p2)
+        self._aggregate("fwd", self.p2, self.z, relu=False)
+        return xin, self.hd, None
+
     def forward(self, train):
+        if self.order == "aggregate_first":
+            return self._forward_aggregate_first(train)
         k = self.k
         keep = self.keep if train else 1.0
         xdrop = None
@@ -280,7 +327,10 @@ class FullBatchGCN(object):
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
         k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
         # layer 1
-        if self.recompute:
+        if self.order == "aggregate_first":
+            # the gated product is the gradient wrt (A_hat X') W1; X needs none
+            k.gemm(self.ax, self.p1, trans_a=True, out=self.g1)            # (A_hat X')^T dZ1
+        elif self.recompute:
             plan = self.plan
             nh = plan.n_halo
             for work in (dp2_work, self._bits_work):
@@ -295,10 +345,11 @@ class FullBatchGCN(object):
             k.spmm(plan.csr, self.p1, out=self.hb, b2=self.wide_halo[:nh] if nh else None)
         else:
             self._aggregate("bwd", self.p1, self.hb, relu=False)         # A^T dH -> dP1
-        if xdrop is not None:
-            k.gemm(xin, self.hb, trans_a=True, out=self.g1, a_dropout=xdrop)  # X'^T dP1, X' regenerated
-        else:
-            k.gemm(xin, self.hb, trans_a=True, out=self.g1)                 # X'^T dP1
+        if self.order != "aggregate_first":
+            if xdrop is not None:
+                k.gemm(xin, self.hb, trans_a=True, out=self.g1, a_dropout=xdrop)  # X'^T dP1, X' regenerated
+            else:
+                k.gemm(xin, self.hb, trans_a=True, out=self.g1)                 # X'^T dP1
         self._allreduce(self.g1)
         self._allreduce(self.g2)
         k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)
@@ -314,5 +365,9 @@ class FullBatchGCN(object):
 
     # work accounting for the benchmark -------------------------------------
     def spmm_units_per_step(self, nnz_global):
-        """nnz x width summed over the four SpMM of one training step."""
+        """nnz x width summed over the SpMM launches of one training step (four
+        in the reference order; the aggregate-first order has no hidden-width
+        backward SpMM)."""
+        if self.order == "aggregate_first":
+            return nnz_global * (self.f + 2 * self.c)
         return nnz_global * (2 * self.h + 2 * self.c)

@@ -239,6 +239,28 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     return out
 
 
+def dropout_rows_philox(x, row_ids, keep, seed, offset, out=None):
+    """Dropout of gathered rows: row i of ``x`` draws the mask of row
+    ``row_ids[i]`` of the [*, W] matrix the mask is defined on (element index
+    ``offset + row_ids[i] * W + c``)."""
+    lib = _lib.load()
+    _check_dense(x, "x")
+    if row_ids.dtype != torch.int32 or row_ids.numel() != x.shape[0] or not row_ids.is_contiguous() or \
+            row_ids.device != x.device:
+        raise ValueError("row_ids: one contiguous int32 per row of x")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _check_dense(out, "out")
+        if out.shape != x.shape:
+            raise ValueError("out must have the shape of x")
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gcnx_dropout_rows_philox_f32(x.shape[0], x.shape[1], _ptr(x), x.stride(0), _ptr(row_ids),
+                                                    float(keep), int(seed) & (2 ** 64 - 1), int(offset),
+                                                    _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 def pack_sign_bits(x, rows=None, out=None):
     """int32 [n, ceil(W/32)]: bit (c % 32) of word (i, c // 32) is set iff
     ``x[rows[i] if rows is not None else i, c] > 0``."""

@@ -121,8 +121,15 @@ class OracleKernels(object):
         out.copy_(t)
         return out
 
+    def dropout_rows_philox(self, x, row_ids, keep, seed, offset, out=None):
+        w = x.shape[1]
+        idx = np.uint64(offset) + row_ids.numpy().astype(np.uint64)[:, None] * np.uint64(w) + \
+            np.arange(w, dtype=np.uint64)[None, :]
+        m = self.torch.from_numpy(self.o.bernoulli_mask_at(idx, keep, seed))
+        return self.dropout_dense(x, m, 1.0 / keep, out=out)
+
     def gemm(self, a, b, trans_a=False, trans_b=False, out=None, gate=None, gate_scale=1.0, a_dropout=None,
-             a_dropout_rows=None, gate_bits=None, **kw):
+             a_dropout_rows=None, gate_bits=None, relu=False, dropout=None, **kw):
         an = a.contiguous().numpy()
         if a_dropout is not None and a_dropout[0] < 1.0:
             keep, seed, offset = a_dropout
@@ -141,6 +148,14 @@ class OracleKernels(object):
                                  self.torch.zeros_like(r))
         if gate is not None:
             r = self.torch.where(gate > 0, r * gate_scale, self.torch.zeros_like(r))
+        if relu:
+            r = self.torch.clamp_min(r, 0)
+        if dropout is not None and dropout[0] < 1.0:
+            keep, seed, offset, ld, col0 = dropout
+            rows = np.arange(r.shape[0], dtype=np.uint64)[:, None]
+            cols = np.arange(r.shape[1], dtype=np.uint64)[None, :]
+            m = self.o.bernoulli_mask_at(np.uint64(offset) + rows * np.uint64(ld) + np.uint64(col0) + cols, keep, seed)
+            r = self.torch.where(self.torch.from_numpy(m != 0), r * np.float32(1.0 / keep), self.torch.zeros_like(r))
         if out is None:
             return r
         out.copy_(r)

@@ -59,11 +59,14 @@ def _dense_tuple(x):
     return (np.stack([r.ravel(), c.ravel()], 1), x.ravel().copy(), (n, f))
 
 
-@pytest.mark.parametrize("hidden,classes", [(16, 7), (128, 16)])
-def test_engine_steps_match_oracle(env, hidden, classes):
+@pytest.mark.parametrize("hidden,classes,order,scale,f", [
+    (16, 7, "reference", 9, 48), (128, 16, "reference", 9, 48),
+    # (A_hat X') W1: the same sums associated the other way (the oracle keeps the
+    # reference order); the second case runs the fused relu + dropout epilogue
+    (16, 7, "aggregate_first", 9, 48), (128, 16, "aggregate_first", 11, 64)])
+def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
-    scale, f = 9, 48
     n = 1 << scale
     a = env["rmat"].rmat_ahat(scale, 8, 123, dev)
     rng = np.random.RandomState(3)
@@ -74,7 +77,7 @@ def test_engine_steps_match_oracle(env, hidden, classes):
     lmask = (rng.random_sample(n) < 0.2).astype(np.uint8)
     T = lambda v: torch.from_numpy(v).to(dev)
     eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
-                                     T(w1), T(w2), seed=123)
+                                     T(w1), T(w2), seed=123, order=order)
     rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
     sup = (np.stack([rows, ci], 1), v, (n, n))
@@ -91,8 +94,11 @@ def test_engine_steps_match_oracle(env, hidden, classes):
         assert abs(got[0] - xent) <= 1e-5 * abs(xent) + 1e-6, (step, got[0], xent)
         assert abs(got[1] - acc) <= 1e-6
         assert np.abs(eng.z.cpu().numpy() - logits).max() <= 2e-5 * np.abs(logits).max()
+        # an Adam step moves every weight by about lr whatever the gradient's size, so
+        # with the other association a near-zero gradient may round the other way
+        wtol = 2e-6 if order == "reference" else 2e-4
         for w_gpu, w_ref in ((eng.w1, orc.w[0][0]), (eng.w2, orc.w[1][0])):
-            assert np.abs(w_gpu.cpu().numpy() - w_ref).max() <= 1e-5 * np.abs(w_ref).max() + 2e-6
+            assert np.abs(w_gpu.cpu().numpy() - w_ref).max() <= 1e-5 * np.abs(w_ref).max() + wtol
     ev = eng.evaluate().cpu().numpy()
     logits, _ = orc.forward()
     xent, _ = env["oracle"].masked_softmax_xent(logits, labels, lmask, want_grad=False)
@@ -144,8 +150,10 @@ def test_spmm_properties_at_scale(env, scale):
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)
 
 
-@pytest.mark.parametrize("halo_mode,features,hidden", [("exchange", 32, 64), ("recompute", 128, 128)])
-def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden):
+@pytest.mark.parametrize("halo_mode,features,hidden,order", [
+    ("exchange", 32, 64, "reference"), ("recompute", 128, 128, "reference"),
+    ("exchange", 128, 128, "aggregate_first")])
+def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden, order):
     """bench.py end to end with 2 ranks sharing the one GPU (gloo rehearsal
     backend, host-staged all-gather; the HIP kernels, the row-range graph
     build, the slabbed gather and the all-reduces are the real ones) against
@@ -156,7 +164,7 @@ def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden):
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     common = ["--scale", "14", "--steps", "3", "--warmup", "0", "--cpu-rows", "0", "--hidden", str(hidden),
-              "--features", str(features)]
+              "--features", str(features), "--order", order]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
                          capture_output=True, text=True, timeout=200, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]

@@ -588,3 +588,18 @@ def test_gemm_output_dropout(env, ta, tb, M, N, K):
     assert np.array_equal(got[m == 0], want[m == 0])
     mag = 2.0 * env["oracle"].gemm_f64(np.abs(a), np.abs(b), bool(ta), bool(tb))
     assert float((np.abs(got.astype(np.float64) - want) / np.maximum(mag, 1e-30)).max()) <= RTOL
+
+
+@pytest.mark.parametrize("n,width,off", [(1000, 256, 4 * 77), (333, 100, 4 * 5), (64, 30, 3)])
+def test_dropout_of_gathered_rows(env, n, width, off):
+    """Row i draws the mask of row row_ids[i]: equals the same rows of the
+    full-matrix dropout."""
+    torch = env["torch"]
+    rng = np.random.RandomState(n)
+    total = 3 * n
+    x = torch.from_numpy(rng.standard_normal((total, width)).astype(np.float32)).to(env["dev"])
+    full = env["ops"].dropout_philox(x.view(-1), 0.5, 13, off).view(total, width)
+    rows = np.sort(rng.choice(total, size=n, replace=False)).astype(np.int32)
+    rt = torch.from_numpy(rows).to(env["dev"])
+    got = env["ops"].dropout_rows_philox(x[rt.long()].contiguous(), rt, 0.5, 13, off)
+    assert torch.equal(got, full[rt.long()])
