@@ -601,6 +601,11 @@ class Session(object):
             if ent is None:
                 # first occurrence: eager (it also warms every cache the graph relies on);
                 # the fed objects are kept alive so that their ids stay unique
+                if len(self._graphs) >= 64:
+                    # a caller that feeds fresh objects every step never replays:
+                    # forget the calls seen once (oldest first) instead of growing
+                    for old_key in [k_ for k_, v_ in self._graphs.items() if "graph" not in v_][:32]:
+                        del self._graphs[old_key]
                 self._graphs[key] = {"refs": (list(flist), list(feed.items()))}
             elif "graph" not in ent:
                 from .sparse import WORKSPACE
