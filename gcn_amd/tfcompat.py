@@ -17,6 +17,7 @@ import argparse
 import contextlib
 import os
 import sys
+import warnings
 
 import numpy as np
 import torch
@@ -607,14 +608,23 @@ class Session(object):
                     for old_key in [k_ for k_, v_ in self._graphs.items() if "graph" not in v_][:32]:
                         del self._graphs[old_key]
                 self._graphs[key] = {"refs": (list(flist), list(feed.items()))}
-            elif "graph" not in ent:
+            elif "graph" not in ent and not ent.get("eager_only"):
                 from .sparse import WORKSPACE
                 graph = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(graph):
-                    ent["results"] = self._execute(flist, feed)
-                ent["graph"] = graph
-                ent["workspace"] = WORKSPACE.buffers()
+                try:
+                    with torch.cuda.graph(graph):
+                        ent["results"] = self._execute(flist, feed)
+                except RuntimeError as exc:
+                    # something in this call cannot be recorded (a host read-back, an
+                    # allocation outside the graph pool): nothing of the recording ran;
+                    # run this call eagerly from now on
+                    ent.pop("results", None)
+                    ent["eager_only"] = True
+                    warnings.warn("hip_graph: this session.run is not recordable, running it eagerly (%s)" % (exc,))
+                else:
+                    ent["graph"] = graph
+                    ent["workspace"] = WORKSPACE.buffers()
         if ent is not None and "graph" in ent:
             ent["graph"].replay()
             self.graph_replays += 1
