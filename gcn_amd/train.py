@@ -37,7 +37,8 @@ def define_flags():
     flags.DEFINE_boolean('chebyshev_recurrence', False,
                          'gcn_cheby: evaluate sum_k T_k(L) P_k by Clenshaw recurrence over the pattern of L '
                          'instead of the explicit T_k matrices (same polynomial, fp32 rounding differs).')
-    flags.DEFINE_boolean('hip_graph', False, 'Record each distinct session.run in a HIP graph and replay it.')
+    flags.DEFINE_boolean('hip_graph', True, 'Record each distinct session.run in a HIP graph and replay it '
+                         '(this loop feeds the same objects every epoch; false = launch every kernel every epoch).')
 
 
 def run(data=None, verbose=True, initial_weights=None, mask_provider=None):
