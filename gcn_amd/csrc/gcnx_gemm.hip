@@ -221,7 +221,13 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
   constexpr int NA_V = (MB * KB) / (4 * kBlock);   // 16-byte A pieces per thread
   // A tile stored [m][k] with a 17-word pitch: lanes 0..31 of a fragment read
   // stride-17 words (conflict free), lanes 32..63 the next k.
-  constexpr int NT = BN / 32;
+  // wavefront grid: 4 x 1 (each 32 rows x BN columns), or 2 x 2 with the 256-column
+  // tile (each 64 x 128: 6 instead of 9 fragment reads per 8 MFMAs)
+  constexpr int WN = BN > 128 ? 2 : 1;
+  constexpr int WM = kWavesPerBlock / WN;
+  constexpr int TM_W = MB / (32 * WM);           // accumulator tiles per wavefront along M
+  constexpr int TN_W = BN / (32 * WN);           // ... along N
+  constexpr int NT = TM_W * TN_W;
   // after the K loop the same memory holds one 32 x 32 output tile per wavefront
   // (36-word pitch) for the 16-byte epilogue
   constexpr int kTilePitch = 36;
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
+  const int wm = w / WN, wn = w % WN;
   const int64_t m0 = (int64_t)blockIdx.x * MB;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
   f16v acc[NT];
@@ -321,12 +328,16 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
 #pragma unroll
     for (int k2 = 0; k2 < KB; k2 += 2) {
       if constexpr (BN >= 128) {
-        const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
+        float af[TM_W], bf[TN_W];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float b = Bs[(k2 + lk) * BN + t * 32 + li];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-        }
+        for (int i = 0; i < TM_W; ++i) af[i] = As[((wm * TM_W + i) * 32 + li) * (KB + 1) + k2 + lk];
+#pragma unroll
+        for (int t = 0; t < TN_W; ++t) bf[t] = Bs[(k2 + lk) * BN + (wn * TN_W + t) * 32 + li];
+#pragma unroll
+        for (int i = 0; i < TM_W; ++i)
+#pragma unroll
+          for (int t = 0; t < TN_W; ++t)
+            acc[i * TN_W + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[t], acc[i * TN_W + t], 0, 0, 0);
       } else {
         const float a = As[(w * 32 + li) * (KB + 1) + k2 + lk];
         const float b = Bs[(k2 + lk) * BN + li];
@@ -341,7 +352,9 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
     // consecutive columns = one Philox block, and stores 16 bytes.
     float *const my = smem + w * (32 * kTilePitch);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) store_tile_relu_dropout(g, acc[t], my, kTilePitch, lane, m0 + w * 32, n0 + t * 32);
+    for (int t = 0; t < NT; ++t)
+      store_tile_relu_dropout(g, acc[t], my, kTilePitch, lane, m0 + (wm * TM_W + t / TN_W) * 32,
+                              n0 + (wn * TN_W + t % TN_W) * 32);
     return;
   }
 #pragma unroll
@@ -349,8 +362,8 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
 #pragma unroll
     for (int rgi = 0; rgi < 16; ++rgi) {
       const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
-      const int64_t gm = m0 + w * 32 + row;
-      const int64_t gn = n0 + t * 32 + li;
+      const int64_t gm = m0 + (wm * TM_W + t / TN_W) * 32 + row;
+      const int64_t gn = n0 + (wn * TN_W + t % TN_W) * 32 + li;
       if (gm >= g.M || gn >= g.N) continue;
       float *dst = g.C + gm * g.ldc + gn;
       *dst = gemm_epilogue(g, acc[t][rgi], dst, gm, gn);
