@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--classes", type=int, default=16)
-    ap.add_argument("--cpu-rows", type=int, default=1 << 20, help="rows of the CPU-baseline slice (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 22, help="rows of the CPU-baseline slice (0 = skip)")
     ap.add_argument("--slab-cols", type=int, default=0)
     ap.add_argument("--verbose", action="store_true", help="progress lines on stderr")
     ap.add_argument("--hang-dump", type=int, default=0,
