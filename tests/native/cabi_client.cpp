@@ -1,0 +1,143 @@
+// A client of the C ABI that knows nothing about Python or PyTorch: device
+// memory from hipMalloc, a stream of its own, the calling sequences of
+// include/gcnx.h (workspace query -> call), results checked against plain host
+// loops in double precision.  Built by gcn_amd/csrc/Makefile into
+// gcn_amd/lib/cabi_client; tests/test_gpu_kernels.py runs it.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gcnx.h"
+
+#define HIP_OK(x)                                                                 \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      std::fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+#define GCNX_OK_(x)                                                               \
+  do {                                                                            \
+    int rc_ = (x);                                                                \
+    if (rc_ != GCNX_OK) {                                                         \
+      std::fprintf(stderr, "%s:%d: status %d: %s\n", __FILE__, __LINE__, rc_, gcnx_last_error()); \
+      return 3;                                                                   \
+    }                                                                             \
+  } while (0)
+
+template <typename T>
+static T *dev_alloc(size_t n) {
+  void *p = nullptr;
+  if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  return static_cast<T *>(p);
+}
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return (uint32_t)(rng_state >> 32);
+}
+static double urand() { return (rnd() >> 8) * (1.0 / 16777216.0) * 2.0 - 1.0; }
+
+int main() {
+  const int64_t n_rows = 5000, n_cols = 4000, nnz = 60000;
+  const int32_t width = 64;
+  const int64_t M = 3000, N = 16, K = 256;
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+
+  // ---- COO -> CSR -> SpMM -------------------------------------------------
+  std::vector<int32_t> row(nnz), col(nnz);
+  std::vector<double> val(nnz);
+  for (int64_t k = 0; k < nnz; ++k) {
+    row[k] = (int32_t)(rnd() % n_rows);
+    col[k] = (int32_t)(rnd() % n_cols);
+    val[k] = urand();
+  }
+  for (int64_t k = 0; k < 3000; ++k) row[k] = 7;   // one long row
+  std::vector<float> b((size_t)n_cols * width);
+  for (auto &v : b) v = (float)urand();
+
+  int32_t *d_row = dev_alloc<int32_t>(nnz), *d_col = dev_alloc<int32_t>(nnz), *d_ci = dev_alloc<int32_t>(nnz);
+  double *d_val = dev_alloc<double>(nnz);
+  int64_t *d_rp = dev_alloc<int64_t>(n_rows + 1);
+  float *d_v = dev_alloc<float>(nnz), *d_b = dev_alloc<float>(b.size()), *d_c = dev_alloc<float>((size_t)n_rows * width);
+  if (!d_row || !d_col || !d_ci || !d_val || !d_rp || !d_v || !d_b || !d_c) return 2;
+  HIP_OK(hipMemcpy(d_row, row.data(), nnz * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_col, col.data(), nnz * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_val, val.data(), nnz * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+
+  size_t ws_bytes = gcnx_csr_from_coo_workspace_bytes(n_rows, nnz);
+  void *ws = dev_alloc<char>(ws_bytes);
+  GCNX_OK_(gcnx_csr_from_coo(n_rows, n_cols, nnz, d_row, d_col, 1, d_val, 1, d_rp, d_ci, d_v, nullptr, ws,
+                             ws_bytes, stream));
+  gcnx_csr a = {n_rows, n_cols, nnz, d_rp, d_ci, d_v};
+  int32_t *d_chunk = dev_alloc<int32_t>((size_t)gcnx_spmm_num_chunks(nnz) + 1);
+  GCNX_OK_(gcnx_spmm_chunk_table(&a, d_chunk, stream));
+  size_t sp_bytes = gcnx_spmm_workspace_bytes(nnz, width);
+  void *sp_ws = dev_alloc<char>(sp_bytes);
+  GCNX_OK_(gcnx_spmm_csr_f32(&a, d_chunk, d_b, width, d_c, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 1,
+                             sp_ws, sp_bytes, stream));
+  std::vector<float> c((size_t)n_rows * width);
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(c.data(), d_c, c.size() * 4, hipMemcpyDeviceToHost));
+
+  std::vector<double> ref((size_t)n_rows * width, 0.0), mag((size_t)n_rows * width, 0.0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const double v = (double)(float)val[k];
+    for (int j = 0; j < width; ++j) {
+      const double t = v * (double)b[(size_t)col[k] * width + j];
+      ref[(size_t)row[k] * width + j] += t;
+      mag[(size_t)row[k] * width + j] += std::fabs(t);
+    }
+  }
+  double worst = 0.0;
+  for (size_t i = 0; i < ref.size(); ++i) {
+    const double want = ref[i] > 0.0 ? ref[i] : 0.0;   // fuse_relu = 1
+    const double err = std::fabs((double)c[i] - want) / (mag[i] > 1e-30 ? mag[i] : 1e-30);
+    if (err > worst) worst = err;
+  }
+  std::printf("spmm relu: worst error %.3g of the summed magnitudes\n", worst);
+  if (!(worst <= 1e-5)) return 1;
+
+  // ---- a wrong call comes back as a status, not as an abort ----------------
+  if (gcnx_spmm_csr_f32(&a, d_chunk, d_b, width, d_c, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 0,
+                        sp_ws, 16, stream) != GCNX_ERR_WORKSPACE) return 1;
+
+  // ---- dense product ---------------------------------------------------------
+  std::vector<float> ha((size_t)M * K), hb((size_t)K * N), hc((size_t)M * N);
+  for (auto &v : ha) v = (float)urand();
+  for (auto &v : hb) v = (float)urand();
+  float *d_ga = dev_alloc<float>(ha.size()), *d_gb = dev_alloc<float>(hb.size()), *d_gc = dev_alloc<float>(hc.size());
+  HIP_OK(hipMemcpy(d_ga, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_gb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  size_t g_bytes = gcnx_gemm_workspace_bytes(0, 0, M, N, K);
+  void *g_ws = dev_alloc<char>(g_bytes);
+  GCNX_OK_(gcnx_gemm_f32(0, 0, M, N, K, d_ga, K, d_gb, N, d_gc, N, 1.0f, 0.0f, 0, g_ws, g_bytes, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(hc.data(), d_gc, hc.size() * 4, hipMemcpyDeviceToHost));
+  worst = 0.0;
+  for (int64_t m = 0; m < M; ++m)
+    for (int64_t n = 0; n < N; ++n) {
+      double s = 0.0, mg = 0.0;
+      for (int64_t k = 0; k < K; ++k) {
+        const double t = (double)ha[m * K + k] * (double)hb[k * N + n];
+        s += t;
+        mg += std::fabs(t);
+      }
+      const double err = std::fabs((double)hc[m * N + n] - s) / mg;
+      if (err > worst) worst = err;
+    }
+  std::printf("gemm: worst error %.3g of the summed magnitudes\n", worst);
+  if (!(worst <= 1e-5)) return 1;
+  std::printf("C ABI client OK (abi %d)\n", gcnx_abi_version());
+  return 0;
+}

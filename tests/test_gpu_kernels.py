@@ -603,3 +603,19 @@ def test_dropout_of_gathered_rows(env, n, width, off):
     rt = torch.from_numpy(rows).to(env["dev"])
     got = env["ops"].dropout_rows_philox(x[rt.long()].contiguous(), rt, 0.5, 13, off)
     assert torch.equal(got, full[rt.long()])
+
+
+def test_cabi_client_without_python(spmm_path):
+    """tests/native/cabi_client.cpp: hipMalloc'd memory, its own stream, the C ABI
+    only (no Python, no PyTorch in the process); it checks SpMM and the dense
+    product against host loops and a status-code path, and exits 0."""
+    import os
+    import subprocess
+    if spmm_path != "default":
+        pytest.skip("separate process: the dispatch knobs of this process do not reach it")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = os.path.join(root, "gcn_amd", "lib", "cabi_client")
+    assert os.path.exists(exe), "build it with make -C gcn_amd/csrc"
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "C ABI client OK" in res.stdout
