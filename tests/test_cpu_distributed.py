@@ -33,7 +33,7 @@ def _problem(scale=7, f=12, hidden=16, classes=5):
     return n, a_hat, x, w1, w2, labels, lmask, hidden, classes
 
 
-def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag=""):
+def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
         CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
         int(lmask.sum()), hidden, classes, T(w1), T(w2), row_begin=rb, n_global=n, seed=5,
         group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank, slab_cols=slab,
-        kernels=OracleKernels(), halo_mode=halo_mode, order=order)
+        kernels=OracleKernels(), halo_mode=halo_mode, order=order, dropout=dropout)
     if world > 1:
         assert eng.recompute == (halo_mode == "recompute" and order == "reference")
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
@@ -111,6 +111,21 @@ def test_aggregate_first_order(tmp_path, world):
     np.testing.assert_allclose(one["ev"], ref["ev"], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(one["w1"], ref["w1"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(one["w2"], ref["w2"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("halo_mode,order", [("recompute", "reference"), ("auto", "aggregate_first")])
+def test_two_ranks_without_dropout(tmp_path, halo_mode, order):
+    """keep = 1: no masks anywhere (the recomputed halo rows use the plain
+    product, the relu gate still travels as sign bits)."""
+    out = str(tmp_path)
+    _run(0, 1, 0, None, out, "auto", 32, order, "", 0.0)
+    mp.spawn(_run, args=(2, _free_port(), 8, out, halo_mode, 32, order, "", 0.0), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "w2_r0.npz"))
+    np.testing.assert_allclose(r0["outs"], one["outs"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r0["ev"], one["ev"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r0["w1"], one["w1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
 
 
 def test_single_rank_matches_model_oracle():
