@@ -112,6 +112,11 @@ class FullBatchGCN(object):
             self.plan_bwd = self.plan if a_bwd_local is None else \
                 HaloPlan(a_bwd_local, self.row_begin, nl, self.world, rank, self._all_to_all, **kw)
             self.slab = int(slab_cols) if slab_cols else min(64, self.h)
+            wide_by_slabs = not agg_first and not self._recompute_feasible(halo_mode)
+            if not wide_by_slabs and not slab_cols:
+                # only class-width operands (and, once, the features) travel in slabs:
+                # keep the staging buffers small
+                self.slab = min(self.slab, max(16, (self.c + 3) // 4 * 4))
             n_halo = max(self.plan.n_halo, self.plan_bwd.n_halo, 1)
             n_send = max(self.plan.n_send, self.plan_bwd.n_send, 1)
             self.halobuf = [e(n_halo * self.slab), e(n_halo * self.slab)]
@@ -129,7 +134,7 @@ class FullBatchGCN(object):
             self.recompute = False
 
     # --------------------------------------------------- halo rows by recompute
-    def _setup_recompute(self, halo_mode):
+    def _recompute_feasible(self, halo_mode):
         if halo_mode not in ("auto", "exchange", "recompute"):
             raise ValueError("halo_mode must be auto, exchange or recompute")
         k, plan = self.k, self.plan
@@ -138,10 +143,14 @@ class FullBatchGCN(object):
         if ok and self.keep < 1.0 and plan.n_halo:
             sup = getattr(k, "gemm_supports_a_dropout", None)
             ok = sup is not None and bool(sup(False, plan.n_halo, self.h, self.f))
-        if not ok:
-            if halo_mode == "recompute":
-                raise ValueError("halo_mode='recompute' is not served for this configuration")
+        if not ok and halo_mode == "recompute":
+            raise ValueError("halo_mode='recompute' is not served for this configuration")
+        return ok
+
+    def _setup_recompute(self, halo_mode):
+        if not self._recompute_feasible(halo_mode):
             return False
+        plan = self.plan
         e = lambda *s, **kw: torch.empty(s, dtype=kw.get("dtype", torch.float32), device=self.dev)
         nh, ns = max(plan.n_halo, 1), max(plan.n_send, 1)
         # resident copy of the remote feature rows this block references (fetched once)
