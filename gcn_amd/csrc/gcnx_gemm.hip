@@ -579,7 +579,9 @@ __global__ __launch_bounds__(kBlock) void gemm_small_k_kernel(const GemmArgs g) 
 // ---------------------------------------------------------------------------
 typedef float __attribute__((ext_vector_type(16))) f16v_;
 
-template <bool TB>
+// GATE: 0 none, 1 float gate, 2 bit gate (a template parameter so that the
+// unrolled epilogue of a full tile carries no branches at all).
+template <bool TB, int GATE>
 __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const GemmArgs g) {
   constexpr int NT = 8;  // 32-column tiles of one 256-column slab
   const int lane = threadIdx.x & 63;
@@ -621,37 +623,68 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
 #pragma unroll
       for (int j = 0; j < 4; ++j) { af[j] = a0[j]; af[4 + j] = a1[j]; }
     }
+    // bit gate: lane i fetches the words of row r0 + i once (one word per tile);
+    // a tile then takes its rows' words with v_readlane
+    uint32_t wb[NT];
+    if constexpr (GATE == 2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        wb[t] = 0u;
+        if (r0 + li < g.M && n0 + 32 * t < g.N) wb[t] = g.gate_bits[(r0 + li) * g.ldbits + ((n0 + 32 * t) >> 5)];
+      }
+    }
+    // Addresses are a wavefront-uniform base (row and tile) plus one per-lane
+    // 32-bit offset that is the same for every row and tile.
+    const int c_off = 4 * lh * (int)g.ldc + li;
+    const int g_off = 4 * lh * (int)g.ldgate + li;
+    const bool rows_full = r0 + 32 <= g.M && g.beta == 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int64_t col = n0 + 32 * t + li;
-      if (n0 + 32 * t >= g.N) break;
-      // the gate / old values of this tile travel while its MFMAs run
-      float gt[16], old[16];
-#pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int64_t row = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
-        gt[rg] = 1.0f;
-        old[rg] = 0.0f;
-        if (row < g.M && col < g.N) {
-          if (g.gate) gt[rg] = g.gate[row * g.ldgate + col];
-          if (g.gate_bits)
-            gt[rg] = ((g.gate_bits[row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? 1.0f : 0.0f;
-          if (g.beta != 0.0f) old[rg] = g.C[row * g.ldc + col];
-        }
-      }
+      const int64_t tc0 = n0 + 32 * t;
+      if (tc0 >= g.N) break;
       f16v_ acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+      if (rows_full && tc0 + 32 <= g.N) {
+        // full tile, beta == 0: no per-element conditions
+        float gt[16];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[t][s], acc, 0, 0, 0);
+        for (int rg = 0; rg < 16; ++rg) {
+          const int ro = (rg & 3) + 8 * (rg >> 2);
+          if constexpr (GATE == 1) gt[rg] = (g.gate + (r0 + ro) * g.ldgate + tc0)[g_off];
+          if constexpr (GATE == 2) {
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wb[t], ro);
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)wb[t], ro + 4);
+            gt[rg] = (((lh ? w1 : w0) >> li) & 1u) ? 1.0f : 0.0f;
+          }
+          if constexpr (GATE == 0) gt[rg] = 1.0f;
+        }
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int64_t row = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
-        if (row < g.M && col < g.N) {
-          float o = g.alpha * acc[rg] + g.beta * old[rg];
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[t][s], acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int ro = (rg & 3) + 8 * (rg >> 2);
+          float o = g.alpha * acc[rg];
           if (g.relu) o = fmaxf(o, 0.0f);
-          if (g.gate || g.gate_bits) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
-          g.C[row * g.ldc + col] = o;
+          if constexpr (GATE != 0) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
+          (g.C + (r0 + ro) * g.ldc + tc0)[c_off] = o;
+        }
+      } else {
+        const int64_t col = tc0 + li;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[t][s], acc, 0, 0, 0);
+        for (int rg = 0; rg < 16; ++rg) {
+          const int64_t row = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+          if (row < g.M && col < g.N) {
+            float *dst = g.C + row * g.ldc + col;
+            float o = g.alpha * acc[rg];
+            if (g.beta != 0.0f) o += g.beta * *dst;
+            if (g.relu) o = fmaxf(o, 0.0f);
+            if constexpr (GATE == 1) o = g.gate[row * g.ldgate + col] > 0.0f ? o * g.gate_scale : 0.0f;
+            if constexpr (GATE == 2)
+              o = ((g.gate_bits[row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? o * g.gate_scale : 0.0f;
+            *dst = o;
+          }
         }
       }
     }
@@ -1025,8 +1058,15 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     int64_t blocks = ceil_div(ceil_div(M, 32), kWavesPerBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div(N, 256));
-    if (trans_b) hipLaunchKernelGGL((gemm_small_k_mfma_kernel<true>), grid, dim3(kBlock), 0, st, g);
-    else hipLaunchKernelGGL((gemm_small_k_mfma_kernel<false>), grid, dim3(kBlock), 0, st, g);
+#define GCNX_SMALLK(TBV)                                                                                  \
+  do {                                                                                                   \
+    if (gate_bits) hipLaunchKernelGGL((gemm_small_k_mfma_kernel<TBV, 2>), grid, dim3(kBlock), 0, st, g);  \
+    else if (gate) hipLaunchKernelGGL((gemm_small_k_mfma_kernel<TBV, 1>), grid, dim3(kBlock), 0, st, g);  \
+    else hipLaunchKernelGGL((gemm_small_k_mfma_kernel<TBV, 0>), grid, dim3(kBlock), 0, st, g);            \
+  } while (0)
+    if (trans_b) GCNX_SMALLK(true);
+    else GCNX_SMALLK(false);
+#undef GCNX_SMALLK
     GCNX_CHECK_LAUNCH();
     return GCNX_OK;
   }

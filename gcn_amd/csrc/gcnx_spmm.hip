@@ -91,11 +91,15 @@ struct SpmmArgs {
   uint64_t drop_offset;
   int64_t drop_ld;
   int64_t drop_col0;
+  // nullable (wide kernel only): sign pattern of the stored output, bit (c % 32) of
+  // word sign_bits[r * ld_sign + c / 32] set <=> stored element (r, c) > 0
+  uint32_t *sign_bits;
+  int64_t ld_sign;
 };
 
 template <int VEC>
-__device__ __forceinline__ void epilogue_store(const SpmmArgs &a, int64_t r, int col0,
-                                               typename vec_of<VEC>::type acc) {
+__device__ __forceinline__ typename vec_of<VEC>::type epilogue_store(const SpmmArgs &a, int64_t r, int col0,
+                                                                     typename vec_of<VEC>::type acc) {
   float *dst = a.C + r * a.ldc + col0;
   typename vec_of<VEC>::type out = acc * a.alpha;
   if (a.beta != 0.0f) out += vload<VEC>(dst) * a.beta;
@@ -115,6 +119,21 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &a, int64_t r, int
     }
   }
   vstore<VEC>(dst, out);
+  return out;
+}
+
+// Lane l holds the stored columns 4l..4l+3 of row r; the 8 lanes of one 32-column
+// word OR their nibbles together with three DPP moves (no LDS traffic) and the
+// first of them stores the word.  Called with whole groups of 8 lanes active
+// (width % 32 == 0).
+__device__ __forceinline__ void store_sign_word(const SpmmArgs &a, int64_t r, int col0, int lane,
+                                                typename vec_of<4>::type v) {
+  int w = ((v[0] > 0.0f ? 1 : 0) | (v[1] > 0.0f ? 2 : 0) | (v[2] > 0.0f ? 4 : 0) | (v[3] > 0.0f ? 8 : 0))
+          << (4 * (lane & 7));
+  w |= __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  w |= __builtin_amdgcn_mov_dpp(w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  w |= __builtin_amdgcn_mov_dpp(w, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the 8
+  if ((lane & 7) == 0) a.sign_bits[r * a.ld_sign + (col0 >> 5)] = (uint32_t)w;
 }
 
 #ifndef GCNX_WIDE_U
@@ -164,7 +183,10 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
       if (rs < 0) {
         vstore<VEC>(pslot, acc);
       } else {
-        epilogue_store<VEC>(a, r, col0, acc);
+        const V out = epilogue_store<VEC>(a, r, col0, acc);
+        if constexpr (VEC == 4) {
+          if (a.sign_bits) store_sign_word(a, r, col0, lane, out);
+        }
       }
     }
     acc = V(0.0f);
@@ -446,7 +468,10 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   const float *p = a.partial + col0;
   V sum = vload<VEC>(p + ((size_t)c * 2 + 1) * a.pwidth);
   for (int64_t cc = c + 1; cc <= cl; ++cc) sum += vload<VEC>(p + (size_t)cc * 2 * a.pwidth);
-  epilogue_store<VEC>(a, r, col0, sum);
+  const V out = epilogue_store<VEC>(a, r, col0, sum);
+  if constexpr (VEC == 4) {
+    if (a.sign_bits) store_sign_word(a, r, col0, lane, out);
+  }
 }
 
 // nnz == 0: every row is empty, C = act(beta * C).
@@ -559,6 +584,13 @@ extern "C" int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row, co
                                  ws, ws_bytes, stream);
 }
 
+static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B, int64_t ldb,
+                     const float *B2, int64_t ldb2, int64_t split_col, float *C, int64_t ldc,
+                     int32_t width, float alpha, float beta, const uint8_t *val_mask,
+                     const int64_t *mask_index, float mask_scale, int fuse_relu,
+                     const gcnx_dropout *out_dropout, uint32_t *sign_bits, int64_t ld_sign, void *ws,
+                     size_t ws_bytes, void *stream);
+
 extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
                                        int64_t ldb, const float *B2, int64_t ldb2,
                                        int64_t split_col, float *C, int64_t ldc, int32_t width,
@@ -566,6 +598,30 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
                                        const int64_t *mask_index, float mask_scale, int fuse_relu,
                                        const gcnx_dropout *out_dropout, void *ws, size_t ws_bytes,
                                        void *stream) {
+  return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, val_mask, mask_index,
+                   mask_scale, fuse_relu, out_dropout, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_spmm_signs_supported(int32_t width) { return (width > 128 && width % 32 == 0) ? 1 : 0; }
+
+extern "C" int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
+                                       int64_t ldb, const float *B2, int64_t ldb2, int64_t split_col,
+                                       float *C, int64_t ldc, int32_t width, float alpha, float beta,
+                                       int fuse_relu, const gcnx_dropout *out_dropout,
+                                       uint32_t *sign_bits, int64_t ld_words, void *ws, size_t ws_bytes,
+                                       void *stream) {
+  GCNX_REQUIRE(sign_bits && ld_words * 32 >= width && gcnx_spmm_signs_supported(width), GCNX_ERR_UNSUPPORTED,
+               "spmm_signs: needs width > 128, width %% 32 == 0 and ld_words * 32 >= width");
+  return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, nullptr, nullptr,
+                   1.0f, fuse_relu, out_dropout, sign_bits, ld_words, ws, ws_bytes, stream);
+}
+
+static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B, int64_t ldb,
+                     const float *B2, int64_t ldb2, int64_t split_col, float *C, int64_t ldc,
+                     int32_t width, float alpha, float beta, const uint8_t *val_mask,
+                     const int64_t *mask_index, float mask_scale, int fuse_relu,
+                     const gcnx_dropout *out_dropout, uint32_t *sign_bits, int64_t ld_sign, void *ws,
+                     size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(a && C, GCNX_ERR_INVALID_ARG, "spmm: null matrix or output");
   GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
                GCNX_ERR_INVALID_ARG, "spmm: negative size");
@@ -606,6 +662,8 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
   k.drop_offset = 0;
   k.drop_ld = 0;
   k.drop_col0 = 0;
+  k.sign_bits = sign_bits;
+  k.ld_sign = ld_sign;
   bool drop_vec_ok = true;
   if (out_dropout && out_dropout->keep < 1.0f) {
     GCNX_REQUIRE(out_dropout->keep > 0.0f && out_dropout->ld >= width && out_dropout->col0 >= 0,
@@ -618,6 +676,7 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
     drop_vec_ok = (out_dropout->offset % 4 == 0) && (out_dropout->ld % 4 == 0) && (out_dropout->col0 % 4 == 0);
   }
 
+  GCNX_REQUIRE(!sign_bits || a->nnz > 0, GCNX_ERR_UNSUPPORTED, "spmm_signs: matrix without nonzeros");
   if (a->nnz == 0) {
     const int64_t total = a->n_rows * (int64_t)width;
     hipLaunchKernelGGL(spmm_empty_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, k);
@@ -671,6 +730,8 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
 #define GCNX_SLOT_U 4       // gather groups in flight per wavefront in the narrow kernel
 #endif
 #define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, GCNX_SLOT_U>), dim3(gx), dim3(kBlock), 0, st, k)
+  GCNX_REQUIRE(!sign_bits || (v4 && lanes > 32), GCNX_ERR_UNSUPPORTED,
+               "spmm_signs: operands must be 16-byte aligned with rows that are multiples of 4 floats");
   if (lanes > 32) {
     gy = (unsigned)ceil_div(lanes, kWave);
     if (v4) hipLaunchKernelGGL((spmm_chunk_kernel<4, GCNX_WIDE_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);

@@ -132,6 +132,12 @@ class FullBatchGCN(object):
         else:
             self.slab = None
             self.recompute = False
+        # sign bits of H' written by the SpMM that produces it: the backward gate
+        # then reads 1 bit per element instead of the element
+        sup_bits = getattr(self.k, "spmm_supports_sign_bits", None)
+        self.hbits = None
+        if not agg_first and sup_bits is not None and sup_bits(self.h) and (self.world == 1 or self.recompute):
+            self.hbits = torch.empty((nl, self.h // 32), dtype=torch.int32, device=self.dev)
 
     # --------------------------------------------------- halo rows by recompute
     def _recompute_feasible(self, halo_mode):
@@ -180,14 +186,15 @@ class FullBatchGCN(object):
                 dst[:plan.n_halo, c0:c0 + nc].copy_(hb)
 
     # ------------------------------------------------------------ collectives
-    def _aggregate(self, which, src, dst, relu, dropout=None):
+    def _aggregate(self, which, src, dst, relu, dropout=None, sign_bits=None):
         """dst = act(A @ [src; halo rows of src]) for A = A_hat (which='fwd') or
         A_hat^T ('bwd'); src, dst are [n_loc, W].  With several ranks the halo
         rows are fetched in column slabs: the exchange of slab s+1 is in flight
         on the communication stream while the SpMM of slab s runs."""
         if self.world == 1:
+            kw = {"sign_bits": sign_bits} if sign_bits is not None else {}
             self.k.spmm(self.a if which == "fwd" else self.at, src, out=dst, relu=relu,
-                        dropout=None if dropout is None else dropout + (dst.shape[1], 0))
+                        dropout=None if dropout is None else dropout + (dst.shape[1], 0), **kw)
             return
         plan = self.plan if which == "fwd" else self.plan_bwd
         w = src.shape[1]
@@ -294,8 +301,9 @@ class FullBatchGCN(object):
                            a_dropout=(keep, self.seed * 2 + 1, off), a_dropout_rows=plan.need)
                 else:
                     k.gemm(self.x_halo[:nh], self.w1, out=self.wide_halo[:nh])
+            kw = {"sign_bits": self.hbits} if (train and self.hbits is not None) else {}
             k.spmm(plan.csr, self.p1, out=self.hd, relu=True, b2=self.wide_halo[:nh] if nh else None,
-                   dropout=None if drop is None else drop + (self.h, 0))
+                   dropout=None if drop is None else drop + (self.h, 0), **kw)
             if train:
                 # the backward pass gates the halo rows of d(A P1) with the sign of
                 # the owners' H': 1 bit per element, sent while layer 2 runs
@@ -304,7 +312,8 @@ class FullBatchGCN(object):
                 self._bits_work = self._all_to_all_start(self.hbits_halo[:nh], self.hbits_send[:plan.n_send],
                                                          plan.recv_counts, plan.send_counts)
         else:
-            self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop)
+            self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop,
+                            sign_bits=self.hbits if (train and self.world == 1) else None)
         hin = self.hd
         k.gemm(hin, self.w2, out=self.p2)
         self._aggregate("fwd", self.p2, self.z, relu=False)
@@ -334,7 +343,10 @@ class FullBatchGCN(object):
                                               plan.recv_counts, plan.send_counts)
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
-        k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
+        if self.hbits is not None:
+            k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate_bits=self.hbits, gate_scale=1.0 / keep)
+        else:
+            k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
         # layer 1
         if self.order == "aggregate_first":
             # the gated product is the gradient wrt (A_hat X') W1; X needs none

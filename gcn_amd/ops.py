@@ -23,7 +23,7 @@ def _check_dense(t, name):
 
 # ------------------------------------------------------------------------ SpMM
 def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False, b2=None,
-         dropout=None):
+         dropout=None, sign_bits=None):
     """``out = act(alpha * A' @ b + beta * out)`` with ``A`` a :class:`Csr`.
     ``mask`` (uint8, in the order of the tuple ``A`` was built from) applies
     sparse dropout to the values on the fly.  Replaces ``dot(x, y, sparse=True)``
@@ -31,7 +31,10 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
     With ``b2`` the dense operand is the row-wise concatenation ``[b; b2]``
     without being assembled (local rows + halo rows of a partitioned run).
     ``dropout=(keep, seed, offset, ld, col0)`` applies dropout to the output in
-    the epilogue (element (r, c) has Philox index offset + r*ld + col0 + c)."""
+    the epilogue (element (r, c) has Philox index offset + r*ld + col0 + c).
+    ``sign_bits`` (int32 [n_rows, width / 32]) also receives the sign pattern of
+    the stored output, the layout :func:`pack_sign_bits` writes
+    (:func:`spmm_supports_sign_bits`)."""
     lib = _lib.load()
     _check_dense(b, "b")
     rows_b2 = 0
@@ -63,6 +66,21 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
         keep, seed, offset, ld, col0 = dropout
         drop = C.byref(_lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld),
                                           int(col0)))
+    if sign_bits is not None:
+        sb = sign_bits
+        if mask is not None or sb.dtype != torch.int32 or sb.dim() != 2 or sb.shape[0] != a.n_rows or \
+                sb.shape[1] * 32 < width or sb.stride(1) != 1 or sb.device != a.device or \
+                not spmm_supports_sign_bits(width):
+            raise ValueError("sign_bits: int32 [n_rows, width / 32] on A's device, width > 128, width % 32 == 0, no mask")
+        with torch.cuda.device(a.device):
+            need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+            ws = WORKSPACE.get(need, a.device)
+            _lib.check(lib.gcnx_spmm_csr_signs_f32(
+                a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
+                _ptr(b2 if rows_b2 else None), b2.stride(0) if rows_b2 else 0, b.shape[0],
+                _ptr(out), out.stride(0), width, float(alpha), float(beta), 1 if relu else 0, drop,
+                _ptr(sb), sb.stride(0), _ptr(ws), ws.numel(), _stream()))
+        return out
     with torch.cuda.device(a.device):
         need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
         ws = WORKSPACE.get(need, a.device)
@@ -72,6 +90,11 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
             _ptr(out), out.stride(0), width, float(alpha), float(beta), _ptr(mask), _ptr(midx),
             float(mask_scale), 1 if relu else 0, drop, _ptr(ws), ws.numel(), _stream()))
     return out
+
+
+def spmm_supports_sign_bits(width):
+    """Whether ``spmm(..., sign_bits=...)`` is served for this operand width."""
+    return bool(_lib.load().gcnx_spmm_signs_supported(int(width)))
 
 
 class _SpmmFn(torch.autograd.Function):

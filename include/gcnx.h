@@ -157,6 +157,23 @@ int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row,
                             const gcnx_dropout *out_dropout /* nullable */,
                             void *ws, size_t ws_bytes, void *stream);
 
+/* The split product that also writes the sign pattern of what it stores:
+ * bit (c % 32) of sign_bits[r * ld_words + c / 32] is set iff stored element
+ * (r, c) > 0 (after activation and dropout).  With the relu + dropout epilogue
+ * this is the whole gate the backward pass needs (gcnx_gemm_bitgated_f32), 32
+ * bytes per 256-wide row instead of re-reading the 1-KiB row.  Wide operands
+ * only (width > 128, width % 32 == 0: gcnx_spmm_signs_supported); no value mask.
+ * replaces: the relu and dropout gradients of gcn/layers.py:226,210 created at
+ * gcn/models.py:58 (their masks). */
+int gcnx_spmm_signs_supported(int32_t width);
+int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                            const float *B, int64_t ldb, const float *B2,
+                            int64_t ldb2, int64_t split_col, float *C,
+                            int64_t ldc, int32_t width, float alpha, float beta,
+                            int fuse_relu, const gcnx_dropout *out_dropout,
+                            uint32_t *sign_bits, int64_t ld_words, void *ws,
+                            size_t ws_bytes, void *stream);
+
 /* ---- halo exchange of a row-partitioned graph (no counterpart in the
  * reference, which is single-process) ---------------------------------------
  * gcnx_halo_plan: `a` holds local rows [row_begin, row_begin + n_local) with

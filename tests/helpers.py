@@ -86,7 +86,10 @@ class OracleKernels(object):
         out.copy_(src[idx.long()])
         return out
 
-    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, **kw):
+    def spmm_supports_sign_bits(self, width):
+        return width % 32 == 0
+
+    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, sign_bits=None, **kw):
         if b2 is not None:
             b = self.torch.cat([b, b2], 0)
         r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
@@ -100,6 +103,8 @@ class OracleKernels(object):
             m = self.o.bernoulli_mask_at(idx, keep, seed)
             r = np.where(m != 0, r * np.float32(1.0 / keep), np.float32(0)).astype(np.float32)
         t = self.torch.from_numpy(r)
+        if sign_bits is not None:
+            self.pack_sign_bits(t, out=sign_bits)
         if out is None:
             return t
         out.copy_(t)

@@ -619,3 +619,27 @@ def test_cabi_client_without_python(spmm_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "C ABI client OK" in res.stdout
+
+
+@pytest.mark.parametrize("n,nnz,width,split", [(3000, 40000, 256, False), (2000, 30000, 160, True),
+                                               (900, 200000, 512, False)])
+def test_spmm_sign_bits(env, n, nnz, width, split):
+    """The sign pattern written by the SpMM epilogue == pack_sign_bits of the
+    stored output, and the stored output is that of the plain call."""
+    torch, dev = env["torch"], env["dev"]
+    rng = np.random.RandomState(n + width)
+    rows, cols, vals = random_coo(rng, n, n, nnz, hub_rows=((5, 3000),), empty_rows=(0, 17))
+    a = env["sparse"].Csr.from_coo(rows, cols, vals, (n, n), dev)
+    b = torch.from_numpy(rng.standard_normal((n, width)).astype(np.float32)).to(dev)
+    assert env["ops"].spmm_supports_sign_bits(width)
+    kw = dict(relu=True, dropout=(0.5, 99, 4 * 1000, width, 0))
+    if split:
+        kw["b2"] = b[n // 2:]
+        b1 = b[:n // 2]
+    else:
+        b1 = b
+    plain = env["ops"].spmm(a, b1, **kw)
+    bits = torch.full((n, width // 32), -1, dtype=torch.int32, device=dev)
+    got = env["ops"].spmm(a, b1, sign_bits=bits, **kw)
+    assert torch.equal(plain, got)
+    assert torch.equal(bits, env["ops"].pack_sign_bits(plain))

@@ -30,6 +30,7 @@ def main():
     g1 = torch.empty((h, h), device=dev)
     g2 = torch.empty((h, c), device=dev)
     drop = (0.5, 7, 0)
+    bits = ops.pack_sign_bits(x)
     cases = [
         ("X.W1 [N,h]x[h,h]", 2.0 * n * h * h, lambda: ops.gemm(x, w1, out=y)),
         ("drop(X).W1", 2.0 * n * h * h, lambda: ops.gemm(x, w1, out=y, a_dropout=drop)),
@@ -39,6 +40,8 @@ def main():
         ("H^T.dP2 [h,N]x[N,c]", 2.0 * n * h * c, lambda: ops.gemm(x, p2, trans_a=True, out=g2)),
         ("dP2.W2^T gated [N,c]x[c,h]", 2.0 * n * h * c,
          lambda: ops.gemm(p2, w2, trans_b=True, out=y, gate=x, gate_scale=2.0)),
+        ("dP2.W2^T bit-gated", 2.0 * n * h * c,
+         lambda: ops.gemm(p2, w2, trans_b=True, out=y, gate_bits=bits, gate_scale=2.0)),
     ]
     for name, flops, fn in cases:
         if args.only and args.only not in name:

@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=8)
     ap.add_argument("--width", type=int, nargs="+", default=[256])
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--signs", action="store_true", help="also time the relu + dropout epilogue without and "
+                    "with the sign-bit output")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -39,6 +41,19 @@ def main():
         print("W=%d: %.3f ms (min %.3f)  nnz*F/s=%.3e  algorithmic %.1f GB/s (%.1f%% of 8 TB/s)" % (
             w, med, ms[0], a.nnz * w / (med * 1e-3), algo / (med * 1e-3) / 1e9,
             algo / (med * 1e-3) / 8e12 * 100), flush=True)
+        if args.signs and ops.spmm_supports_sign_bits(w):
+            bits = torch.empty((a.n_rows, w // 32), dtype=torch.int32, device=dev)
+            drop = (0.5, 7, 0, w, 0)
+            for name, kw in (("relu+dropout", {}), ("relu+dropout+signs", {"sign_bits": bits})):
+                ops.spmm(a, b, out=out, relu=True, dropout=drop, **kw)
+                torch.cuda.synchronize()
+                ev[0].record()
+                for i in range(args.iters):
+                    ops.spmm(a, b, out=out, relu=True, dropout=drop, **kw)
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
+                print("W=%d %s: %.3f ms (min %.3f)" % (w, name, ms[len(ms) // 2], ms[0]), flush=True)
         del b, out
 
 
