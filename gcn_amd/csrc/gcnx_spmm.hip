@@ -298,14 +298,25 @@ __global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
   V acc = V(0.0f);
   float *const pslot = a.partial + (size_t)c * 2 * a.pwidth + col0;
 
+  // Sum over the slots: offsets below 16 lanes rotate inside a 16-lane row with a
+  // DPP move (no LDS traffic), offsets 16 and 32 cross rows with a shuffle.
+  auto xadd = [&](float v, int off) -> float {
+    if (off == 1) return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    if (off == 2) return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    if (off == 4) return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xF, 0xF, true));  // row_ror:4
+    if (off == 8) return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8
+    return v + __shfl_xor(v, off, kWave);
+  };
   auto reduce_slots = [&](V x) -> V {
+    // rotations by 8 then 4 sum the lanes {l, l+4, l+8, l+12} of a row for LW == 4;
+    // in general: every power of two from LW up to 8 as a rotation, 16 and 32 as xor
 #pragma unroll
     for (int off = LW; off < kWave; off <<= 1) {
       if constexpr (VEC == 1) {
-        x += __shfl_xor(x, off, kWave);
+        x = xadd(x, off);
       } else {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) x[i] += __shfl_xor(x[i], off, kWave);
+        for (int i = 0; i < VEC; ++i) x[i] = xadd(x[i], off);
       }
     }
     return x;
