@@ -261,9 +261,10 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
     for (int i = 0; i < NA_V; ++i) {
       const int e = tid + i * kBlock;
       const int m = e / (KB / 4), q = e % (KB / 4);
-      const int64_t gm = m0 + m;
-      ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
-      if (gm < g.M) ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
+      // rows past the end read the last row instead of branching: their results
+      // are never stored
+      const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;
+      ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
     }
     if constexpr (!TB && BN >= 128) {
 #pragma unroll
@@ -294,8 +295,10 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
       const int e = tid + i * kBlock;
       const int m = e / (KB / 4), q = e % (KB / 4);
       f4v v = ra[i];
-      if (g.adrop_keep < 1.0f && m0 + m < g.M)
-        v = drop4(g, v, g.adrop_rows ? (int64_t)g.adrop_rows[m0 + m] : m0 + m, kk + q * 4);
+      if (g.adrop_keep < 1.0f) {
+        const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;
+        v = drop4(g, v, g.adrop_rows ? (int64_t)g.adrop_rows[gm] : gm, kk + q * 4);
+      }
       float *d = As + m * (KB + 1) + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -357,6 +360,20 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
                               n0 + (wn * TN_W + t % TN_W) * 32);
     return;
   }
+  if (g.beta == 0.0f && !g.gate && !g.gate_bits && m0 + MB <= g.M && n0 + BN <= g.N) {
+    // whole block tile in range, plain epilogue: wavefront-uniform base per (row,
+    // tile) plus one per-lane offset, no per-element conditions
+    const int c_off = 4 * lk * (int)g.ldc + li;
+    const float lo = g.relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float *const base = g.C + (m0 + (wm * TM_W + t / TN_W) * 32) * g.ldc + n0 + (wn * TN_W + t % TN_W) * 32;
+#pragma unroll
+      for (int rgi = 0; rgi < 16; ++rgi)
+        (base + ((rgi & 3) + 8 * (rgi >> 2)) * g.ldc)[c_off] = fmaxf(g.alpha * acc[t][rgi], lo);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -415,12 +432,19 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_tn_kernel(
   f4v ra[2], rb[NBV];
   float rbs[2];
   auto load_tiles = [&](int64_t kk) {
+    // a whole K-step inside the split (all but possibly the last one): no
+    // per-row conditions (wavefront-uniform test)
+    const bool whole = kk + BK <= kend;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
-      ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
-      if (kk + k < kend) ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      if (whole) {
+        ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      } else {
+        ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if (kk + k < kend) ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+      }
       if constexpr (BN < 128)
         rbs[i] = (kk + k < kend && n0 + q < g.N) ? g.B[(kk + k) * g.ldb + n0 + q] : 0.0f;
     }
@@ -429,8 +453,12 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_tn_kernel(
       for (int i = 0; i < NBV; ++i) {
         const int e = tid + i * kBlock;
         const int k = e / (BN / 4), q = e % (BN / 4);
-        rb[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
-        if (kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+        if (whole) {
+          rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+        } else {
+          rb[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+          if (kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+        }
       }
     }
   };
@@ -440,7 +468,7 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_tn_kernel(
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
       f4v v = ra[i];
-      if (g.adrop_keep < 1.0f && kk + k < kend) v = drop4(g, v, kk + k, m0 + q * 4);
+      if (g.adrop_keep < 1.0f) v = drop4(g, v, kk + k, m0 + q * 4);   // rows past kend hold zeros
       *reinterpret_cast<f4v *>(As + k * BM + q * 4) = v;
       if constexpr (BN < 128) Bs[k * BN + q] = rbs[i];
     }
