@@ -308,7 +308,13 @@ class FullBatchGCN(object):
                 # the backward pass gates the halo rows of d(A P1) with the sign of
                 # the owners' H': 1 bit per element, sent while layer 2 runs
                 if plan.n_send:
-                    k.pack_sign_bits(self.hd, rows=plan.send_idx, out=self.hbits_send[:plan.n_send])
+                    if self.hbits is not None:
+                        # the SpMM already wrote the sign words of every local row: pick
+                        # the requested rows (32 bytes each; a bit-preserving copy)
+                        k.gather_rows(self.hbits.view(torch.float32), plan.send_idx,
+                                      self.hbits_send[:plan.n_send].view(torch.float32))
+                    else:
+                        k.pack_sign_bits(self.hd, rows=plan.send_idx, out=self.hbits_send[:plan.n_send])
                 self._bits_work = self._all_to_all_start(self.hbits_halo[:nh], self.hbits_send[:plan.n_send],
                                                          plan.recv_counts, plan.send_counts)
         else:

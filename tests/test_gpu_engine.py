@@ -151,7 +151,7 @@ def test_spmm_properties_at_scale(env, scale):
 
 
 @pytest.mark.parametrize("halo_mode,features,hidden,order", [
-    ("exchange", 32, 64, "reference"), ("recompute", 128, 128, "reference"),
+    ("exchange", 32, 64, "reference"), ("recompute", 128, 256, "reference"),
     ("exchange", 128, 128, "aggregate_first")])
 def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden, order):
     """bench.py end to end with 2 ranks sharing the one GPU (gloo rehearsal
