@@ -55,6 +55,17 @@ def cpu_baseline(a, b_dev, rows, width):
     t1 = time.perf_counter()
     oracle.spmm_csr(rp, ci, v, b, omp=True)
     t2 = time.perf_counter()
+    scipy_entry = None
+    try:                                     # third figure: scipy's csr @ dense (one thread, its own C++ loop)
+        import scipy.sparse as sp
+        m = sp.csr_matrix((v, ci, rp), shape=(rows, b.shape[0]))
+        t3 = time.perf_counter()
+        m @ b
+        t4 = time.perf_counter()
+        scipy_entry = {"value": nnz * width / (t4 - t3), "cores": 1, "seconds": t4 - t3,
+                       "kind": "scipy.sparse csr_matrix @ ndarray"}
+    except ImportError:
+        pass
     model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -71,7 +82,7 @@ def cpu_baseline(a, b_dev, rows, width):
         "seconds": t1 - t0,
         "all_cores": {"value": nnz * width / (t2 - t1), "cores": oracle.max_threads(),
                       "seconds": t2 - t1, "kind": "port (OpenMP over rows)"},
-        "host_cpu": model, "host_cpu_count": os.cpu_count(),
+        "scipy": scipy_entry, "host_cpu": model, "host_cpu_count": os.cpu_count(),
     }
 
 

@@ -37,6 +37,9 @@ def define_flags():
     flags.DEFINE_boolean('chebyshev_recurrence', False,
                          'gcn_cheby: evaluate sum_k T_k(L) P_k by Clenshaw recurrence over the pattern of L '
                          'instead of the explicit T_k matrices (same polynomial, fp32 rounding differs).')
+    flags.DEFINE_boolean('device_eigval', False,
+                         'gcn_cheby: largest Laplacian eigenvalue by a Lanczos iteration over the HIP SpMM '
+                         'instead of ARPACK on the host (about 1e-6 relative difference).')
     flags.DEFINE_boolean('hip_graph', True, 'Record each distinct session.run in a HIP graph and replay it '
                          '(this loop feeds the same objects every epoch; false = launch every kernel every epoch).')
 
@@ -61,7 +64,12 @@ def run(data=None, verbose=True, initial_weights=None, mask_provider=None):
         num_supports = 1
         model_func = GCN
     elif FLAGS.model == 'gcn_cheby':
-        support = chebyshev_polynomials(adj, FLAGS.max_degree)
+        lmax = None
+        if FLAGS.device_eigval:
+            from .spectral import largest_eigval_of_adjacency
+            lmax = largest_eigval_of_adjacency(adj)
+        support = chebyshev_polynomials(adj, FLAGS.max_degree) if lmax is None else \
+            chebyshev_polynomials(adj, FLAGS.max_degree, largest_eigval=lmax)
         num_supports = 1 + FLAGS.max_degree
         model_func = GCN
     elif FLAGS.model == 'dense':

@@ -45,6 +45,7 @@ def _setup(model, dataset, epochs, hidden=16):
     F.learning_rate, F.dropout, F.weight_decay, F.early_stopping, F.max_degree = 0.01, 0.5, 5e-4, 10, 3
     F.hip_graph = False
     F.chebyshev_recurrence = False
+    F.device_eigval = False
     return F
 
 
@@ -269,3 +270,34 @@ def test_chebyshev_recurrence_mode(dataset):
     print("chebyshev recurrence, %s: worst relative loss difference %.3g" % (dataset, worst))
     ref, got, orc, _ = _run_both("gcn_cheby", dataset, 200, recurrence=True)
     assert abs(got["test_acc"] - ref["test_acc"]) <= 0.005 + 1e-9, (got["test_acc"], ref["test_acc"])
+
+
+@pytest.mark.parametrize("dataset", ["cora", "citeseer", "random"])
+def test_device_lanczos_eigenvalue(dataset):
+    """lmax of the normalised Laplacian from the Lanczos iteration over the HIP
+    SpMM against the eigenvalue the reference's ARPACK call returned (stored
+    with the golden Chebyshev vectors) or, for a random graph, ARPACK run here.
+    The SpMM is fp32: the bar is 1e-5 relative (measured: about 1e-7)."""
+    import os
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import eigsh
+    from gcn_amd import spectral, utils
+    from gcn_amd.sparse import Csr
+    if dataset == "random":
+        rng = np.random.RandomState(5)
+        m = sp.random(3000, 3000, density=0.002, random_state=rng, format="csr")
+        adj = ((m + m.T) > 0).astype(np.float64).tocsr()
+        want = float(eigsh(sp.eye(3000) - utils.normalize_adj(adj), 1, which="LM")[0][0])
+    else:
+        adj = utils.load_graph(dataset)
+        gold = os.path.join(os.path.dirname(__file__), "golden", "cheby3_%s.npz" % dataset)
+        want = float(np.load(gold)["lambda_max"])
+    s = Csr.from_scipy(utils.normalize_adj(adj).tocsr(), device="cuda")
+    got, iters, resid = spectral.largest_laplacian_eigval(s)
+    assert abs(got - want) <= 1e-5 * want, (got, want, iters, resid)
+    assert resid <= 1e-5
+    assert abs(spectral.largest_eigval_of_adjacency(adj) - got) <= 1e-12
+    # the value is accepted where the reference's own estimate goes
+    polys = utils.chebyshev_polynomials(adj, 2, largest_eigval=got)
+    ref = utils.chebyshev_polynomials(adj, 2, largest_eigval=want)
+    np.testing.assert_allclose(polys[2][1], ref[2][1], rtol=1e-4, atol=1e-6)
