@@ -528,7 +528,9 @@ def test_pack_sign_bits(env, n, width):
 
 
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 1, 5001, 128, 16), (0, 0, 700, 33, 20),
-                                         (0, 0, 4096, 256, 128), (0, 1, 2048, 64, 7)])
+                                         (0, 0, 4096, 256, 128), (0, 1, 2048, 64, 7),
+                                         # split-K weight-gradient shapes and the skinny streaming kernels
+                                         (1, 0, 256, 64, 5000), (1, 0, 256, 16, 40000), (0, 0, 2048, 16, 128)])
 def test_gemm_bit_gate_equals_float_gate(env, ta, tb, M, N, K):
     """The gate read as one bit per element gives the bits of the float gate."""
     torch = env["torch"]
