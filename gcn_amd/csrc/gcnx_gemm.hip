@@ -695,7 +695,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
           float o = g.alpha * acc[rg];
           if (g.relu) o = fmaxf(o, 0.0f);
           if constexpr (GATE != 0) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
-          (g.C + (r0 + ro) * g.ldc + tc0)[c_off] = o;
+          __builtin_nontemporal_store(o, g.C + (r0 + ro) * g.ldc + tc0 + c_off);
         }
       } else {
         const int64_t col = tc0 + li;
