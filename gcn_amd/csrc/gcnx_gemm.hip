@@ -162,6 +162,26 @@ __global__ __launch_bounds__(kBlock) void gemm_reduce_kernel(const GemmArgs g) {
   *dst = gemm_epilogue(g, s, dst, e / g.N, e % g.N);
 }
 
+// First stage of a long reduction: plane j of `stage` = the sum of planes
+// [j * kReduceFan, (j + 1) * kReduceFan) of `partial`, added in plane order.
+// With hundreds of splits and a small C the single-stage kernel above is a few
+// hundred dependent loads on a handful of threads; two stages keep the order of
+// the additions fixed (reproducible) and every load coalesced.
+constexpr int kReduceFan = 16;
+constexpr int kReduceStagedFrom = 32;   // split counts from here on take two stages
+__global__ __launch_bounds__(kBlock) void gemm_reduce_stage_kernel(const float *__restrict__ partial,
+                                                                    float *__restrict__ stage, int64_t mn,
+                                                                    int splits, int planes_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= mn * planes_out) return;
+  const int64_t e = t % mn;
+  const int j = (int)(t / mn);
+  const int z1 = (j + 1) * kReduceFan < splits ? (j + 1) * kReduceFan : splits;
+  float s = 0.0f;
+  for (int z = j * kReduceFan; z < z1; ++z) s += partial[(int64_t)z * mn + e];
+  stage[t] = s;
+}
+
 // ---------------------------------------------------------------------------
 // MFMA kernel:  C[M,N] = A[M,K] * B[K,N]  (no transposes), N % 32 == 0,
 // K % 16 == 0.  Workgroup = 4 wavefronts, block tile 128 x BN (BN = 128);
@@ -936,6 +956,31 @@ static int choose_splits(int64_t M, int64_t N, int64_t K) {
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Workspace of a product cut into `splits` partial results: the partial planes
+// and, for long reductions, the planes of the first reduction stage.
+static size_t split_ws_bytes(int splits, int64_t M, int64_t N) {
+  if (splits <= 1) return 0;
+  const size_t planes = (size_t)splits + (splits >= kReduceStagedFrom ? (size_t)ceil_div(splits, kReduceFan) : 0);
+  return planes * (size_t)M * (size_t)N * sizeof(float);
+}
+
+// Adds the partial planes in order and applies the epilogue (one or two launches).
+static int launch_split_reduce(GemmArgs g, hipStream_t st) {
+  const int64_t mn = g.M * g.N;
+  if (g.splits >= kReduceStagedFrom) {
+    const int planes = (int)ceil_div(g.splits, kReduceFan);
+    float *stage = g.partial + (size_t)g.splits * (size_t)mn;
+    hipLaunchKernelGGL(gemm_reduce_stage_kernel, dim3((unsigned)ceil_div(mn * planes, kBlock)), dim3(kBlock), 0, st,
+                       g.partial, stage, mn, g.splits, planes);
+    GCNX_CHECK_LAUNCH();
+    g.partial = stage;
+    g.splits = planes;
+  }
+  hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(mn, kBlock)), dim3(kBlock), 0, st, g);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
 }  // namespace gcnx
 
 using namespace gcnx;
@@ -949,7 +994,7 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
   int s = choose_splits(M, N, K);
   if (trans_a && !trans_b && skinny_tn_shape(M, N, K)) s = std::max(s, skinny_tn_splits(M, K));
   if (trans_a && !trans_b && tn_mfma_shape(M, N, K)) s = std::max(s, tn_mfma_splits(M, N, K));
-  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+  return split_ws_bytes(s, M, N);
 }
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
@@ -1131,7 +1176,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   if (skinny_tn) {
     const int sp = skinny_tn_splits(M, K);
     if (sp > 1) {
-      const size_t need = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+      const size_t need = split_ws_bytes(sp, M, N);
       GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
                    "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
       g.partial = static_cast<float *>(ws);
@@ -1141,10 +1186,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     hipLaunchKernelGGL(gemm_skinny_tn_kernel, dim3((unsigned)ceil_div(M, 256), 1u, (unsigned)g.splits),
                        dim3(kBlock), 0, st, g);
     GCNX_CHECK_LAUNCH();
-    if (g.splits > 1) {
-      hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
-      GCNX_CHECK_LAUNCH();
-    }
+    if (g.splits > 1) return launch_split_reduce(g, st);
     return GCNX_OK;
   }
 
@@ -1179,7 +1221,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   if (tn_ok) {
     const int sp = tn_mfma_splits(M, N, K);
     if (sp > 1) {
-      const size_t need = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+      const size_t need = split_ws_bytes(sp, M, N);
       GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
                    "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
       g.partial = static_cast<float *>(ws);
@@ -1199,10 +1241,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                          dim3(kBlock), 0, st, g);
     }
     GCNX_CHECK_LAUNCH();
-    if (g.splits > 1) {
-      hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
-      GCNX_CHECK_LAUNCH();
-    }
+    if (g.splits > 1) return launch_split_reduce(g, st);
     return GCNX_OK;
   }
 
@@ -1210,7 +1249,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                "gemm: dropout on A is only fused into the MFMA kernels (tall A, a weight dimension >= 64)");
   const int splits = choose_splits(M, N, K);
   if (splits > 1) {
-    const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+    const size_t need = split_ws_bytes(splits, M, N);
     GCNX_REQUIRE(ws && ws_bytes >= need, GCNX_ERR_WORKSPACE,
                  "gemm: workspace of %zu bytes required, got %zu", need, ws_bytes);
     g.partial = static_cast<float *>(ws);
@@ -1225,9 +1264,6 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   else if (trans_a && !trans_b) hipLaunchKernelGGL((gemm_tile_kernel<true, false>), grid, dim3(kBlock), 0, st, g);
   else hipLaunchKernelGGL((gemm_tile_kernel<true, true>), grid, dim3(kBlock), 0, st, g);
   GCNX_CHECK_LAUNCH();
-  if (g.splits > 1) {
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
-    GCNX_CHECK_LAUNCH();
-  }
+  if (g.splits > 1) return launch_split_reduce(g, st);
   return GCNX_OK;
 }
