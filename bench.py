@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E (spec)
+MFMA_F32_PEAK = 157.3e12  # flop/s, dense fp32 matrix rate of MI355X (256 CUs x 256 flop/clk x 2.4 GHz)
 
 
 def algorithmic_bytes(nnz, n_rows, width):
@@ -212,6 +213,7 @@ def main():
         s.record()
         e.record()
     ev_used = []
+    gemm_ev = []
     real_spmm = ops.spmm
 
     class Timed(object):
@@ -231,6 +233,20 @@ def main():
                 ev_used.append((s, e))
                 return out
             return real_spmm(aa, b, **kw)
+
+        def gemm(self, x, y, **kw):
+            # the two 2*N*F*hidden-flop products of the step (X' W1 and X'^T dP1)
+            # get an event pair each (they run on torch's current stream)
+            big = x.shape[0] == n_loc and x.shape[1] == args.features and y.shape[-1] == args.hidden and \
+                (bool(kw.get("trans_a")) == (y.shape[0] == n_loc))
+            if Timed.armed and big and args.order == "reference" and len(gemm_ev) < n_ev:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = ops.gemm(x, y, **kw)
+                e.record()
+                gemm_ev.append((s, e, "tn" if kw.get("trans_a") else "nn"))
+                return out
+            return ops.gemm(x, y, **kw)
 
     model.k = Timed()
 
@@ -304,6 +320,18 @@ def main():
                 "launches_timed": len(ms), "kernel_nnzF_per_s": a.nnz * args.hidden / avg,
                 "compulsory_bytes_per_launch": 8 * a.nnz + 8 * a.n_rows * args.hidden + 8 * (a.n_rows + 1),
             }
+        if gemm_ev:
+            flops = 2.0 * n_loc * args.features * args.hidden
+            per = {}
+            for s_, e_, kind in gemm_ev:
+                per.setdefault(kind, []).append(s_.elapsed_time(e_) * 1e-3)
+            result["roofline_dense"] = {
+                kind: {"bound": "mfma", "kernel": ("gemm_mfma_kernel<256> (dropout(X) W1)" if kind == "nn" else
+                                                   "gemm_mfma_tn_kernel<256> (dropout(X)^T dP1)"),
+                       "achieved": flops / (sum(v) / len(v)) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                       "unit": "TFLOP/s", "frac": flops / (sum(v) / len(v)) / MFMA_F32_PEAK,
+                       "flops_per_launch": flops, "avg_launch_ms": sum(v) / len(v) * 1e3, "launches_timed": len(v)}
+                for kind, v in per.items()}
         if args.cpu_rows and world == 1:
             try:
                 b_dev = model.p1  # any resident [N, hidden] fp32 operand
