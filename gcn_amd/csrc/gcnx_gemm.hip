@@ -1123,6 +1123,17 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     g.adrop_rows = a_rows;
   }
 
+  if (K == 0) {
+    // empty inner dimension: C = epilogue(0) (beta * C, gates, relu); the operands
+    // may be null, so no product kernel is launched
+    GCNX_REQUIRE(!want_odrop && !want_adrop, GCNX_ERR_UNSUPPORTED, "gemm: fused dropout with K = 0");
+    GCNX_REQUIRE(M * N / kBlock < 0x7fffffffll, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
+    g.splits = 0;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)ceil_div(M * N, kBlock)), dim3(kBlock), 0, st, g);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+
   // tiny inner dimension, wide output: the streaming kernel
   const bool small_k = !trans_a && !want_adrop && K >= 1 && K <= 32 && N >= 64 && (N % 4 == 0) &&
                        M >= 1024 && (ldc % 4 == 0) && aligned16(C) &&

@@ -633,12 +633,13 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
                      const int64_t *mask_index, float mask_scale, int fuse_relu,
                      const gcnx_dropout *out_dropout, uint32_t *sign_bits, int64_t ld_sign, void *ws,
                      size_t ws_bytes, void *stream) {
-  GCNX_REQUIRE(a && C, GCNX_ERR_INVALID_ARG, "spmm: null matrix or output");
+  GCNX_REQUIRE(a, GCNX_ERR_INVALID_ARG, "spmm: null matrix");
   GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
                GCNX_ERR_INVALID_ARG, "spmm: negative size");
   GCNX_REQUIRE(a->n_rows < INT32_MAX && a->n_cols < INT32_MAX, GCNX_ERR_UNSUPPORTED,
                "spmm: more than 2^31-1 rows or columns");
-  if (a->n_rows == 0 || width == 0) return GCNX_OK;
+  if (a->n_rows == 0 || width == 0) return GCNX_OK;   // an empty output may come with a null pointer
+  GCNX_REQUIRE(C, GCNX_ERR_INVALID_ARG, "spmm: null output");
   GCNX_REQUIRE(ldc >= width, GCNX_ERR_INVALID_ARG, "spmm: ldc < width");
   hipStream_t st = as_stream(stream);
 

@@ -645,3 +645,58 @@ def test_spmm_sign_bits(env, n, nnz, width, split):
     got = env["ops"].spmm(a, b1, sign_bits=bits, **kw)
     assert torch.equal(plain, got)
     assert torch.equal(bits, env["ops"].pack_sign_bits(plain))
+
+
+@pytest.mark.parametrize("M,N", [(5, 3), (4096, 256), (700, 64)])
+def test_gemm_empty_inner_dimension(env, M, N):
+    """K = 0: the product is the zero matrix, so C = beta * C (then relu);
+    shapes that would otherwise take the MFMA kernels included."""
+    torch = env["torch"]
+    a = torch.empty((M, 0), device=env["dev"])
+    b = torch.empty((0, N), device=env["dev"])
+    got = env["ops"].gemm(a, b)
+    assert got.shape == (M, N) and float(got.abs().max()) == 0.0
+    c = torch.randn((M, N), device=env["dev"])
+    want = torch.clamp_min(c * 0.5, 0)
+    got = env["ops"].gemm(a, b, out=c.clone(), beta=0.5, relu=True)
+    assert torch.equal(got, want)
+
+
+def test_gemm_and_spmm_with_no_rows(env):
+    """M = 0 / an operand without columns: nothing is launched, shapes are kept."""
+    torch = env["torch"]
+    dev = env["dev"]
+    got = env["ops"].gemm(torch.empty((0, 16), device=dev), torch.randn((16, 8), device=dev))
+    assert got.shape == (0, 8)
+    got = env["ops"].gemm(torch.randn((16, 4), device=dev), torch.empty((4, 0), device=dev))
+    assert got.shape == (16, 0)
+
+
+def test_degenerate_sizes_are_no_ops(env):
+    """Zero rows / zero width / zero elements through every op: no launch with
+    an empty grid, no fault, shapes kept."""
+    import scipy.sparse as sp
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    # a matrix with rows but no nonzeros, and an operand without columns
+    a = Csr.from_scipy(sp.csr_matrix((6, 5), dtype=np.float32), device=dev)
+    assert float(ops.spmm(a, torch.randn((5, 8), device=dev)).abs().max()) == 0.0
+    assert ops.spmm(a, torch.empty((5, 0), device=dev)).shape == (6, 0)
+    m = sp.random(50, 40, density=0.1, format="csr", dtype=np.float32, random_state=1)
+    b = Csr.from_scipy(m, device=dev)
+    assert ops.spmm(b, torch.empty((40, 0), device=dev)).shape == (50, 0)
+    # element-wise helpers on empty tensors
+    e = torch.empty((0, 16), device=dev)
+    assert ops.dropout_philox(e, 0.5, 1, 0).shape == (0, 16)
+    assert ops.pack_sign_bits(e).shape[0] == 0
+    idx = torch.empty((0,), dtype=torch.int32, device=dev)
+    out = ops.gather_rows(torch.randn((4, 16), device=dev), idx, torch.empty((0, 16), device=dev))
+    assert out.shape == (0, 16)
+    z = torch.empty((0, 7), device=dev)
+    # the loss over zero rows is undefined (a mean over nothing): a clean error, not a launch
+    from gcn_amd._lib import GcnxError
+    with pytest.raises(GcnxError):
+        ops.masked_softmax_xent(z, z.clone(), torch.empty((0,), dtype=torch.uint8, device=dev), want_grad=False)
+    w = torch.empty((0,), device=dev)
+    ops.adam_step(w, w.clone(), w.clone(), w.clone(), 0.01, 1)
+    torch.cuda.synchronize()
