@@ -56,10 +56,10 @@ __global__ __launch_bounds__(kBlock) void final_sum_kernel(int nb, const double 
 __global__ __launch_bounds__(kBlock) void xent_rows_kernel(
     int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
     const float *__restrict__ labels, int64_t ldl, const uint8_t *__restrict__ mask,
-    const double *__restrict__ msum_p, float *__restrict__ grad, int64_t ldg,
+    const double *__restrict__ msum_p, double msum_known, float *__restrict__ grad, int64_t ldg,
     double *__restrict__ loss_part, double *__restrict__ hit_part) {
   __shared__ double sh[kWavesPerBlock];
-  const double msum = *msum_p;
+  const double msum = msum_known > 0.0 ? msum_known : *msum_p;   // a total given by the caller needs no counting pass
   const float wgt = msum > 0.0 ? (float)(1.0 / msum) : 0.0f;
   double loss = 0.0, hit = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -105,11 +105,11 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
     int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
     const float *__restrict__ labels, int64_t ldl, const uint8_t *__restrict__ mask,
-    const double *__restrict__ msum_p, float *__restrict__ grad, int64_t ldg,
+    const double *__restrict__ msum_p, double msum_known, float *__restrict__ grad, int64_t ldg,
     double *__restrict__ loss_part, double *__restrict__ hit_part) {
   __shared__ double sh[kWavesPerBlock];
   constexpr int RPB = kBlock / G;  // rows per block and pass
-  const double msum = *msum_p;
+  const double msum = msum_known > 0.0 ? msum_known : *msum_p;
   const float wgt = msum > 0.0 ? (float)(1.0 / msum) : 0.0f;
   const int sub = threadIdx.x % G;
   const bool in = sub < nc;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
 }
 
 __global__ __launch_bounds__(kBlock) void xent_final_kernel(int nb, const double *__restrict__ ws_msum,
+                                                           double msum_known,
                                                            const double *__restrict__ loss_part,
                                                            const double *__restrict__ hit_part,
                                                            float *__restrict__ out) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void xent_final_kernel(int nb, const double
   l = block_sum(l, sh);
   h = block_sum(h, sh);
   if (threadIdx.x == 0) {
-    const double m = *ws_msum;
+    const double m = msum_known > 0.0 ? msum_known : *ws_msum;
     out[0] = m > 0.0 ? (float)(l / m) : 0.0f;
     out[1] = m > 0.0 ? (float)(h / m) : 0.0f;
   }
@@ -469,8 +470,6 @@ extern "C" size_t gcnx_xent_workspace_bytes(int64_t n) {
   return (size_t)(1 + 3 * (size_t)xent_blocks(n < 0 ? 0 : n)) * sizeof(double);
 }
 
-__global__ void set_double_kernel(double *dst, double v) { *dst = v; }
-
 extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const float *logits,
                                             int64_t ld, const float *labels, int64_t ldl,
                                             const uint8_t *mask, double mask_total,
@@ -486,18 +485,17 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
   const int nb = xent_blocks(n);
   double *w = static_cast<double *>(ws);
   double *msum = w, *cnt = w + 1, *lp = w + 1 + nb, *hp = w + 1 + 2 * nb;
-  if (mask_total > 0.0) {
-    hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, st, msum, mask_total);
-  } else {
+  const double known = mask_total > 0.0 ? mask_total : 0.0;
+  if (known == 0.0) {
     hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(kBlock), 0, st, n, mask, cnt);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(kBlock), 0, st, nb, cnt, msum);
   }
 #define GCNX_XENT(G)                                                                          \
   hipLaunchKernelGGL((xent_rows_group_kernel<G>), dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, \
-                     ld, labels, ldl, mask, msum, grad, ldg, lp, hp)
+                     ld, labels, ldl, mask, msum, known, grad, ldg, lp, hp)
   if (n_class > 64) {
     hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
-                       ldl, mask, msum, grad, ldg, lp, hp);
+                       ldl, mask, msum, known, grad, ldg, lp, hp);
   } else if (n_class > 32) GCNX_XENT(64);
   else if (n_class > 16) GCNX_XENT(32);
   else if (n_class > 8) GCNX_XENT(16);
@@ -506,7 +504,7 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
   else if (n_class > 1) GCNX_XENT(2);
   else GCNX_XENT(1);
 #undef GCNX_XENT
-  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, lp, hp, out_loss_acc);
+  hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, known, lp, hp, out_loss_acc);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

@@ -371,10 +371,12 @@ def masked_softmax_xent(logits, labels, mask, want_grad=True, mask_total=0.0, gr
 class _XentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, mask):
-        out, grad = masked_softmax_xent(logits.contiguous(), labels, mask, want_grad=True)
+        # a mask uploaded by the session carries its count of set entries, which
+        # saves the counting pass (two launches) on every step
+        out, grad = masked_softmax_xent(logits.contiguous(), labels, mask, want_grad=True,
+                                        mask_total=float(getattr(mask, "mask_total", 0.0)))
         ctx.save_for_backward(grad)
-        loss = out[0].clone()
-        acc = out[1].clone()
+        loss, acc = out[0], out[1]
         ctx.mark_non_differentiable(acc)
         return loss, acc
 

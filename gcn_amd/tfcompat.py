@@ -547,6 +547,7 @@ class Session(object):
                 out = arr[()].item()
             elif arr.dtype == np.bool_ or np.issubdtype(arr.dtype, np.integer):
                 out = torch.from_numpy(np.ascontiguousarray(arr != 0).astype(np.uint8)).to(device())
+                out.mask_total = float(np.count_nonzero(arr))   # read by the masked loss
             else:
                 out = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device())
         self._cache[key] = (value, out)
