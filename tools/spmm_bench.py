@@ -17,10 +17,23 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--signs", action="store_true", help="also time the relu + dropout epilogue without and "
                     "with the sign-bit output")
+    ap.add_argument("--relabel", choices=["none", "degree"], default="none",
+                    help="degree: renumber the vertices by descending degree first (hub rows of the operand "
+                    "become neighbours in memory)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     t0 = time.time()
     a = rmat.rmat_ahat(args.scale, args.edge_factor, 123, dev)
+    if args.relabel == "degree":
+        from gcn_amd.sparse import Csr
+        deg = a.row_ptr[1:] - a.row_ptr[:-1]
+        order = torch.argsort(deg, descending=True, stable=True)
+        new_id = torch.empty_like(order)
+        new_id[order] = torch.arange(a.n_rows, device=dev)
+        rows = torch.repeat_interleave(torch.arange(a.n_rows, device=dev), deg)
+        a = Csr.from_coo(new_id[rows].to(torch.int32), new_id[a.col_idx.long()].to(torch.int32), a.val,
+                         (a.n_rows, a.n_cols), device=dev)
+        del deg, order, new_id, rows
     torch.cuda.synchronize()
     print("graph: n=%d nnz=%d max_deg=%d build %.2fs" % (
         a.n_rows, a.nnz, int((a.row_ptr[1:] - a.row_ptr[:-1]).max()), time.time() - t0), flush=True)
