@@ -95,6 +95,20 @@ struct SpmmArgs {
   // word sign_bits[r * ld_sign + c / 32] set <=> stored element (r, c) > 0
   uint32_t *sign_bits;
   int64_t ld_sign;
+  // factored dense operand (spmm_factored_kernel): row c of B is not stored but
+  // formed as  gate(c, j) ? fscale * sum_k D[c, k] * W(k, j) : 0  with
+  // W(k, j) = Wm[k * w_sk + j * w_sj]; rows >= split come from D2 / gbits2
+  const float *D;
+  int64_t ldd;
+  const float *D2;
+  int64_t ldd2;
+  const float *Wm;
+  int64_t w_sk, w_sj;
+  const uint32_t *gbits;
+  int64_t ldgb;
+  const uint32_t *gbits2;
+  int64_t ldgb2;
+  float fscale;
 };
 
 template <int VEC>
@@ -252,6 +266,140 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
   if (r < a.n_rows && rs < nk && active) {
     vstore<VEC>(pslot + (rs < 0 ? 0 : a.pwidth), acc);
   }
+}
+
+// The wide kernel with a FACTORED dense operand: B = gate .* (D * W) * fscale with
+// D [n_cols, 16] and W [16, width] (the backward pass of a layer that follows a
+// relu + dropout: B = d(loss)/d(H') gated by the sign pattern of H').  B is never
+// materialised: for every nonzero the wavefront reads the 64-byte row of D with
+// one scalar load (the column index is wavefront-uniform) and the 32-bit gate
+// word of its columns, and forms its four elements of the row with 64 FMAs
+// against weights held in registers -- 96 bytes fetched per nonzero instead of a
+// 1-KiB row, paid for with vector arithmetic the memory-bound kernel has to
+// spare.  The sum over k is a chain of fused multiply-adds from zero in the
+// order in which the two-kernel path feeds k to its matrix instruction, so both
+// paths give the same bits.
+constexpr int kFactoredInner = 16;
+typedef float __attribute__((ext_vector_type(16))) f16s;
+typedef const f16s __attribute__((address_space(4))) *const_f16s_ptr;
+
+template <int U>
+__global__ __launch_bounds__(kBlock, 2) void spmm_factored_kernel(const SpmmArgs a) {
+  typedef typename vec_of<4>::type V;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wid;
+  if (c >= a.n_chunks) return;
+  const int col0 = (int)blockIdx.y * (kWave * 4) + lane * 4;
+  const bool active = col0 < a.width;
+
+  const int chunk = a.chunk;
+  const int64_t n0 = c * (int64_t)chunk;
+  const int64_t left = a.nnz - n0;
+  const int nk = left < (int64_t)chunk ? (int)left : chunk;
+
+  // weights of this lane's four columns
+  V w[kFactoredInner];
+#pragma unroll
+  for (int k = 0; k < kFactoredInner; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[k][j] = active ? a.Wm[k * a.w_sk + (col0 + j) * a.w_sj] : 0.0f;
+  }
+  const int word = col0 >> 5, shift = col0 & 31;
+
+  int64_t r = a.chunk_row[c * a.chunk_mul];
+  int64_t rbase = r;
+  auto load_row_ends = [&](int64_t rb) -> int {
+    const int64_t rr = rb + 1 + lane;
+    if (rr > a.n_rows) return kRowEndBeyond;
+    const int64_t e = a.row_ptr[rr] - n0;
+    return e > (int64_t)chunk ? chunk + 1 : (int)e;
+  };
+  int re_v = load_row_ends(rbase);
+  int re = rl_i(re_v, 0);
+  int rs;
+  {
+    const int64_t s0 = a.row_ptr[r] - n0;
+    rs = s0 < 0 ? -1 : (int)s0;
+  }
+  V acc = V(0.0f);
+  float *const pslot = a.partial + (size_t)c * 2 * a.pwidth + col0;
+
+  auto close_row = [&]() {
+    if (active) {
+      if (rs < 0) vstore<4>(pslot, acc);
+      else vstore<4>(a.C + r * a.ldc + col0, acc);
+    }
+    acc = V(0.0f);
+    rs = re;
+    ++r;
+    int idx = (int)(r - rbase);
+    if (idx == kWave) {
+      rbase = r;
+      re_v = load_row_ends(rbase);
+      idx = 0;
+    }
+    re = rl_i(re_v, idx);
+  };
+
+  auto load_batch = [&](int kb, int &cols, float &vals) {
+    const int k = kb + lane;
+    cols = 0;
+    vals = 0.0f;
+    if (k < nk) {
+      cols = a.col_idx[n0 + k];
+      vals = a.val[n0 + k];
+    }
+  };
+  int cols_n;
+  float vals_n;
+  load_batch(0, cols_n, vals_n);
+
+  for (int kb = 0; kb < nk; kb += kWave) {
+    const int cols = cols_n;
+    const float vals = vals_n;
+    if (kb + kWave < nk) load_batch(kb + kWave, cols_n, vals_n);
+    const int jn = (nk - kb) < kWave ? (nk - kb) : kWave;
+    for (int j = 0; j < jn; j += U) {
+      f16s d[U];
+      uint32_t gw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = (j + u) < jn ? (j + u) : (jn - 1);
+        const int cc = rl_i(cols, jj);
+        const bool far = cc >= a.split;
+        const float *drow = far ? a.D2 + (int64_t)(cc - a.split) * a.ldd2 : a.D + (int64_t)cc * a.ldd;
+        const uint32_t *grow = far ? a.gbits2 + (int64_t)(cc - a.split) * a.ldgb2 : a.gbits + (int64_t)cc * a.ldgb;
+        // constant address space + uniform address: one s_load_dwordx16
+        d[u] = *reinterpret_cast<const_f16s_ptr>(reinterpret_cast<uintptr_t>(drow));
+        gw[u] = active ? grow[word] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j + u < jn) {
+          const int k = kb + j + u;
+          while (k == re) close_row();
+          const float v = rl_f(vals, j + u);
+          V t = V(0.0f);
+#pragma unroll
+          for (int q = 0; q < kFactoredInner; ++q) {
+            // the order in which gemm_small_k_mfma_kernel feeds k to the matrix
+            // instruction (step s takes k = 8 (s / 4) + s % 4 and that + 4)
+            const int kk = 8 * (q >> 3) + 4 * (q & 1) + ((q >> 1) & 3);
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) t[jx] = __builtin_fmaf(d[u][kk], w[kk][jx], t[jx]);
+          }
+          const uint32_t bits = gw[u] >> shift;
+          V g;
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) g[jx] = ((bits >> jx) & 1u) ? t[jx] * a.fscale : 0.0f;
+          acc += g * v;
+        }
+      }
+    }
+  }
+  while (re <= nk) close_row();
+  if (r < a.n_rows && rs < nk && active) vstore<4>(pslot + (rs < 0 ? 0 : a.pwidth), acc);
 }
 
 // Narrow dense operands (at most 32 lanes wide): the wavefront is cut into
@@ -769,6 +917,91 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   if (k.n_chunks > 1) {
     if (v4) hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     else hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    GCNX_CHECK_LAUNCH();
+  }
+  return GCNX_OK;
+}
+
+#ifndef GCNX_FACTORED_U
+#define GCNX_FACTORED_U 3   // nonzeros whose operand rows are in flight per wavefront (16 scalar registers each)
+#endif
+
+extern "C" int gcnx_spmm_factored_supported(int32_t width, int32_t inner) {
+  return (inner == kFactoredInner && width >= 64 && width % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *D,
+                                          int64_t ldd, const uint32_t *gate_bits, int64_t ld_words,
+                                          const float *D2, int64_t ldd2, const uint32_t *gate_bits2,
+                                          int64_t ld_words2, int64_t split_col, const float *W, int64_t ldw,
+                                          int trans_w, int32_t inner, float gate_scale, float *C,
+                                          int64_t ldc, int32_t width, void *ws, size_t ws_bytes,
+                                          void *stream) {
+  GCNX_REQUIRE(a, GCNX_ERR_INVALID_ARG, "spmm_factored: null matrix");
+  GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0, GCNX_ERR_INVALID_ARG,
+               "spmm_factored: negative size");
+  GCNX_REQUIRE(a->n_rows < INT32_MAX && a->n_cols < INT32_MAX, GCNX_ERR_UNSUPPORTED,
+               "spmm_factored: more than 2^31-1 rows or columns");
+  GCNX_REQUIRE(gcnx_spmm_factored_supported(width, inner), GCNX_ERR_UNSUPPORTED,
+               "spmm_factored: needs inner == %d, width >= 64 and width %% 32 == 0", kFactoredInner);
+  if (a->n_rows == 0) return GCNX_OK;
+  GCNX_REQUIRE(C && ldc >= width && (ldc % 4 == 0) && aligned16(C), GCNX_ERR_INVALID_ARG,
+               "spmm_factored: C must be 16-byte aligned with ldc >= width, ldc %% 4 == 0");
+  GCNX_REQUIRE(W && ldw >= (trans_w ? inner : width), GCNX_ERR_INVALID_ARG, "spmm_factored: bad W");
+  hipStream_t st = as_stream(stream);
+  SpmmArgs k = {};
+  k.n_rows = a->n_rows;
+  k.nnz = a->nnz;
+  k.chunk = chunk_for(a->nnz);
+  k.chunk_mul = k.chunk / kChunkUnit;
+  k.n_chunks = a->nnz <= 0 ? 0 : ceil_div(a->nnz, k.chunk);
+  k.row_ptr = a->row_ptr;
+  k.col_idx = a->col_idx;
+  k.val = a->val;
+  k.chunk_row = chunk_row;
+  k.split = INT32_MAX;
+  k.C = C;
+  k.ldc = ldc;
+  k.width = width;
+  k.pwidth = partial_ld(width);
+  k.alpha = 1.0f;
+  k.mscale = 1.0f;
+  k.partial = static_cast<float *>(ws);
+  k.drop_keep = 1.0f;
+  if (a->nnz == 0) {   // every row empty: C = 0
+    hipLaunchKernelGGL(spmm_empty_kernel, dim3((unsigned)ceil_div(a->n_rows * (int64_t)width, 256)), dim3(256), 0,
+                       st, k);
+    GCNX_CHECK_LAUNCH();
+    return GCNX_OK;
+  }
+  GCNX_REQUIRE(a->row_ptr && a->col_idx && a->val && chunk_row, GCNX_ERR_INVALID_ARG, "spmm_factored: null array");
+  GCNX_REQUIRE(split_col >= 0 && (split_col == 0 || (D && gate_bits && ldd >= inner && ld_words * 32 >= width)),
+               GCNX_ERR_INVALID_ARG, "spmm_factored: bad D / gate words");
+  GCNX_REQUIRE((reinterpret_cast<uintptr_t>(D) & 3) == 0 && (reinterpret_cast<uintptr_t>(D2) & 3) == 0,
+               GCNX_ERR_INVALID_ARG, "spmm_factored: D must be 4-byte aligned");
+  if (split_col < a->n_cols) {
+    GCNX_REQUIRE(D2 && gate_bits2 && ldd2 >= inner && ld_words2 * 32 >= width, GCNX_ERR_INVALID_ARG,
+                 "spmm_factored: second operand missing or too narrow");
+    k.split = (int32_t)split_col;
+  }
+  const size_t need = gcnx_spmm_workspace_bytes(a->nnz, width);
+  GCNX_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GCNX_ERR_WORKSPACE,
+               "spmm_factored: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
+  GCNX_REQUIRE(k.n_chunks / kWavesPerBlock < INT32_MAX, GCNX_ERR_UNSUPPORTED, "spmm_factored: too many chunks");
+  k.D = D; k.ldd = ldd; k.D2 = D2; k.ldd2 = ldd2;
+  k.gbits = gate_bits; k.ldgb = ld_words; k.gbits2 = gate_bits2; k.ldgb2 = ld_words2;
+  k.Wm = W;
+  k.w_sk = trans_w ? 1 : ldw;
+  k.w_sj = trans_w ? ldw : 1;
+  k.fscale = gate_scale;
+  const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
+  const unsigned gy = (unsigned)ceil_div(width, kWave * 4);
+  if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
+  hipLaunchKernelGGL((spmm_factored_kernel<GCNX_FACTORED_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+  GCNX_CHECK_LAUNCH();
+  if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
+  if (k.n_chunks > 1) {
+    hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     GCNX_CHECK_LAUNCH();
   }
   return GCNX_OK;

@@ -138,6 +138,12 @@ class FullBatchGCN(object):
         self.hbits = None
         if not agg_first and sup_bits is not None and sup_bits(self.h) and (self.world == 1 or self.recompute):
             self.hbits = torch.empty((nl, self.h // 32), dtype=torch.int32, device=self.dev)
+        # with the sign words at hand the hidden-width backward product runs with a
+        # factored operand: the rows of d(A P1) are formed inside the SpMM from the
+        # class-width rows of dP2 and never stored
+        sup_f = getattr(self.k, "spmm_supports_factored", None)
+        self.factored_bwd = bool(self.hbits is not None and self.keep > 0.0 and sup_f is not None and
+                                 sup_f(self.h, self.c))
 
     # --------------------------------------------------- halo rows by recompute
     def _recompute_feasible(self, halo_mode):
@@ -349,7 +355,9 @@ class FullBatchGCN(object):
                                               plan.recv_counts, plan.send_counts)
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
-        if self.hbits is not None:
+        if self.factored_bwd:
+            pass                            # formed per nonzero inside the SpMM below
+        elif self.hbits is not None:
             k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate_bits=self.hbits, gate_scale=1.0 / keep)
         else:
             k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
@@ -364,12 +372,21 @@ class FullBatchGCN(object):
                 if work is not None:
                     work.wait()
             self._bits_work = None
-            if nh:
-                # the same gated product for the halo rows, from the received rows
-                # of dP2 and the received sign bits of the owners' H'
-                k.gemm(self.dp2_halo[:nh], self.w2, trans_b=True, out=self.wide_halo[:nh],
-                       gate_bits=self.hbits_halo[:nh], gate_scale=1.0 / keep)
-            k.spmm(plan.csr, self.p1, out=self.hb, b2=self.wide_halo[:nh] if nh else None)
+            if self.factored_bwd:
+                # local and halo rows of d(A P1) alike from dP2 rows and sign words
+                k.spmm_factored(plan.csr, self.dp2, self.w2, self.hbits, gate_scale=1.0 / keep, trans_w=True,
+                                out=self.hb, d2=self.dp2_halo[:nh] if nh else None,
+                                gate_bits2=self.hbits_halo[:nh] if nh else None)
+            else:
+                if nh:
+                    # the same gated product for the halo rows, from the received rows
+                    # of dP2 and the received sign bits of the owners' H'
+                    k.gemm(self.dp2_halo[:nh], self.w2, trans_b=True, out=self.wide_halo[:nh],
+                           gate_bits=self.hbits_halo[:nh], gate_scale=1.0 / keep)
+                k.spmm(plan.csr, self.p1, out=self.hb, b2=self.wide_halo[:nh] if nh else None)
+        elif self.factored_bwd:
+            k.spmm_factored(self.at, self.dp2, self.w2, self.hbits, gate_scale=1.0 / keep, trans_w=True,
+                            out=self.hb)                                    # A^T dH -> dP1, dH never stored
         else:
             self._aggregate("bwd", self.p1, self.hb, relu=False)         # A^T dH -> dP1
         if self.order != "aggregate_first":

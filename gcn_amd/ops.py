@@ -97,6 +97,52 @@ def spmm_supports_sign_bits(width):
     return bool(_lib.load().gcnx_spmm_signs_supported(int(width)))
 
 
+def spmm_supports_factored(width, inner):
+    """Whether ``spmm_factored`` is served for this operand width / inner size."""
+    return bool(_lib.load().gcnx_spmm_factored_supported(int(width), int(inner)))
+
+
+def spmm_factored(a, d, w, gate_bits, gate_scale=1.0, trans_w=False, out=None, d2=None, gate_bits2=None):
+    """``out = A @ G`` with ``G = where(bit, gate_scale * (D @ op(W)), 0)`` formed
+    on the fly (never stored).  ``d`` [n_local_cols, inner] and ``gate_bits``
+    (int32 [n_local_cols, width/32]) cover the first columns of ``a``; ``d2`` /
+    ``gate_bits2`` the remaining ones (halo rows).  ``w`` is [inner, width], or
+    [width, inner] with ``trans_w``."""
+    lib = _lib.load()
+    _check_dense(d, "d")
+    _check_dense(w, "w")
+    inner = d.shape[1]
+    width = w.shape[0] if trans_w else w.shape[1]
+    if (w.shape[1] if trans_w else w.shape[0]) != inner:
+        raise ValueError("inner dimensions differ: d %s, w %s" % (tuple(d.shape), tuple(w.shape)))
+    if gate_bits.dtype != torch.int32 or gate_bits.shape[0] != d.shape[0] or gate_bits.shape[1] * 32 < width:
+        raise ValueError("gate_bits must be int32 [rows of d, ceil(width / 32)]")
+    split = d.shape[0]
+    if d2 is not None and d2.shape[0] > 0:
+        _check_dense(d2, "d2")
+        if gate_bits2 is None or gate_bits2.dtype != torch.int32 or gate_bits2.shape[0] != d2.shape[0] or \
+                gate_bits2.shape[1] * 32 < width or d2.shape[1] != inner:
+            raise ValueError("d2 / gate_bits2 do not match d / gate_bits")
+        n_cols = split + d2.shape[0]
+    else:
+        d2, gate_bits2, n_cols = None, None, split
+    if n_cols != a.n_cols:
+        raise ValueError("operand rows (%d) != matrix columns (%d)" % (n_cols, a.n_cols))
+    if out is None:
+        out = torch.empty((a.n_rows, width), dtype=torch.float32, device=d.device)
+    elif tuple(out.shape) != (a.n_rows, width) or out.stride(1) != 1:
+        raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (a.n_rows, width)))
+    with torch.cuda.device(d.device):
+        need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+        ws = WORKSPACE.get(need, d.device)
+        _lib.check(lib.gcnx_spmm_csr_factored_f32(
+            a.struct_ref(), _ptr(a.chunk_row), _ptr(d), d.stride(0), _ptr(gate_bits), gate_bits.stride(0),
+            _ptr(d2), d2.stride(0) if d2 is not None else 0, _ptr(gate_bits2),
+            gate_bits2.stride(0) if gate_bits2 is not None else 0, split, _ptr(w), w.stride(0), int(trans_w),
+            inner, float(gate_scale), _ptr(out), out.stride(0), width, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 class _SpmmFn(torch.autograd.Function):
     """y = act(A' @ b).  Gradient w.r.t. b only: the sparse operands of the
     reference are placeholders, no gradient reaches their values
@@ -578,6 +624,6 @@ def profile_spmm_events(start, stop):
     lib.gcnx_profile_spmm_events(a, b)
 
 
-__all__ = ["Csr", "spmm", "spmm_autograd", "gemm", "gemm_supports_a_dropout", "gemm_autograd", "masked_softmax_xent",
+__all__ = ["Csr", "spmm", "spmm_factored", "spmm_supports_factored", "spmm_autograd", "gemm", "gemm_supports_a_dropout", "gemm_autograd", "masked_softmax_xent",
            "masked_softmax_xent_autograd", "bernoulli_mask", "dropout_dense",
            "dropout_dense_autograd", "relu_dropout_bwd", "dropout_philox", "relu_dropout_bwd_philox", "philox_uniform", "gather_rows", "adam_step"]

@@ -174,6 +174,34 @@ int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row,
                             uint32_t *sign_bits, int64_t ld_words, void *ws,
                             size_t ws_bytes, void *stream);
 
+/* SpMM with a FACTORED dense operand:  C = A * G  where row c of G is never
+ * stored but formed for every nonzero that references it,
+ *   G[c, j] = bit(c, j) ? gate_scale * sum_{k < inner} D[c, k] * op(W)[k, j] : 0,
+ * bit(c, j) = bit (j % 32) of gate_bits[c * ld_words + j / 32]; op(W) = W
+ * ([inner, width], ld ldw) or, with trans_w, W^T (W stored [width, inner]).
+ * Rows c >= split_col of D / gate_bits come from D2 / gate_bits2 (row
+ * c - split_col): the halo rows received from peers.  This is the backward
+ * pass  A_hat^T * ((H' > 0) ? (dP2 * W2^T) / keep : 0)  in one kernel: 96 bytes
+ * fetched per nonzero instead of a 1-KiB row of a stored intermediate, and the
+ * gated product (gcnx_gemm_bitgated_f32) is not run at all.  The k-sum is an
+ * ascending chain of fused multiply-adds from zero, as in the two-kernel path,
+ * so both give the same bits.  Served for inner == 16, width >= 64,
+ * width % 32 == 0 (gcnx_spmm_factored_supported); workspace as for
+ * gcnx_spmm_csr_f32 at this width.
+ * replaces: the gradient of tf.sparse_tensor_dense_matmul composed with the
+ * relu / dropout / tf.matmul gradients of layer 2 (gcn/layers.py:210,215,219,226
+ * as differentiated at gcn/models.py:58). */
+int gcnx_spmm_factored_supported(int32_t width, int32_t inner);
+int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                               const float *D, int64_t ldd,
+                               const uint32_t *gate_bits, int64_t ld_words,
+                               const float *D2, int64_t ldd2,
+                               const uint32_t *gate_bits2, int64_t ld_words2,
+                               int64_t split_col, const float *W, int64_t ldw,
+                               int trans_w, int32_t inner, float gate_scale,
+                               float *C, int64_t ldc, int32_t width, void *ws,
+                               size_t ws_bytes, void *stream);
+
 /* ---- halo exchange of a row-partitioned graph (no counterpart in the
  * reference, which is single-process) ---------------------------------------
  * gcnx_halo_plan: `a` holds local rows [row_begin, row_begin + n_local) with

@@ -110,6 +110,16 @@ class OracleKernels(object):
         out.copy_(t)
         return out
 
+    def spmm_supports_factored(self, width, inner):
+        return inner == 16 and width >= 64 and width % 32 == 0
+
+    def spmm_factored(self, a, d, w, gate_bits, gate_scale=1.0, trans_w=False, out=None, d2=None, gate_bits2=None):
+        if d2 is not None and d2.shape[0]:
+            d = self.torch.cat([d, d2], 0)
+            gate_bits = self.torch.cat([gate_bits, gate_bits2], 0)
+        g = self.gemm(d, w, trans_b=trans_w, gate_bits=gate_bits, gate_scale=gate_scale)
+        return self.spmm(a, g, out=out)
+
     def gemm_supports_a_dropout(self, trans_a, M, N, K):
         return True
 

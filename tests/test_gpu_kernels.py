@@ -700,3 +700,55 @@ def test_degenerate_sizes_are_no_ops(env):
     w = torch.empty((0,), device=dev)
     ops.adam_step(w, w.clone(), w.clone(), w.clone(), 0.01, 1)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,nnz,width,halo", [(3000, 40000, 256, 0), (5000, 90000, 128, 700), (900, 9000, 64, 0),
+                                               (4000, 200000, 512, 1500)])
+def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
+    """A @ gate(D W^T) with the operand formed per nonzero against the stored
+    intermediate (bit-gated product, then SpMM): same bits; and against the
+    fp64 yardstick.  Hub rows, empty rows, a halo part of the operand."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(n + width)
+    n_cols = n + halo
+    rows, cols, vals = random_coo(rng, n, n_cols, nnz, hub_rows=((7, 3000),), empty_rows=(0, 11, n - 1))
+    a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n_cols), device=dev)
+    d = torch.from_numpy(rng.standard_normal((n_cols, 16)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((width, 16)) * 0.3).astype(np.float32)).to(dev)     # W2 [hidden, classes]
+    hsign = torch.from_numpy(np.maximum(rng.standard_normal((n_cols, width)), 0).astype(np.float32)).to(dev)
+    bits = ops.pack_sign_bits(hsign)
+    assert ops.spmm_supports_factored(width, 16)
+    stored = ops.gemm(d, w, trans_b=True, gate_bits=bits, gate_scale=2.0)          # [n_cols, width]
+    want = ops.spmm(a, stored)
+    if halo:
+        got = ops.spmm_factored(a, d[:n].contiguous(), w, bits[:n].contiguous(), gate_scale=2.0, trans_w=True,
+                                d2=d[n:].contiguous(), gate_bits2=bits[n:].contiguous())
+    else:
+        got = ops.spmm_factored(a, d, w, bits, gate_scale=2.0, trans_w=True)
+    if width > 128:
+        assert torch.equal(got, want)      # both walk a row's nonzeros in order, lane-private sums
+    else:
+        # at these widths the plain SpMM splits a row's nonzeros over lane groups
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # W given as [inner, width]
+    got2 = ops.spmm_factored(a, d[:n].contiguous(), w.t().contiguous(), bits[:n].contiguous(), gate_scale=2.0,
+                             d2=d[n:].contiguous() if halo else None,
+                             gate_bits2=bits[n:].contiguous() if halo else None)
+    assert torch.equal(got2, got)
+    # fp64 yardstick: the whole expression in fp64, error measured against the
+    # size of its terms  sum_i |a_i| * scale * sum_k |d_k w_k|
+    import scipy.sparse as sp
+    on = hsign.cpu().numpy() > 0
+    dn, wn = d.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64)
+    g64 = np.where(on, 2.0 * (dn @ wn.T), 0.0)
+    gmag = np.where(on, 2.0 * (np.abs(dn) @ np.abs(wn).T), 0.0)
+    rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy().astype(np.float64)
+    m = sp.csr_matrix((v, ci, rp), shape=(n, n_cols))
+    assert_close_to_f64(got.cpu().numpy(), m @ g64, abs(m) @ gmag, what="factored spmm")
+
+
+def test_spmm_factored_rejects_unsupported(env):
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    assert not ops.spmm_supports_factored(256, 8)
+    assert not ops.spmm_supports_factored(48, 16)

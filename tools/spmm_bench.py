@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--signs", action="store_true", help="also time the relu + dropout epilogue without and "
                     "with the sign-bit output")
+    ap.add_argument("--factored", action="store_true", help="time A (gate .* (D W^T)) as bit-gated product + SpMM "
+                    "and as the one-kernel factored SpMM (inner 16)")
     ap.add_argument("--relabel", choices=["none", "degree"], default="none",
                     help="degree: renumber the vertices by descending degree first (hub rows of the operand "
                     "become neighbours in memory)")
@@ -67,6 +69,29 @@ def main():
                 torch.cuda.synchronize()
                 ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
                 print("W=%d %s: %.3f ms (min %.3f)" % (w, name, ms[len(ms) // 2], ms[0]), flush=True)
+        if args.factored and ops.spmm_supports_factored(w, 16):
+            d = torch.rand((a.n_cols, 16), device=dev) - 0.5
+            w2 = torch.rand((w, 16), device=dev) - 0.5
+            bits = ops.pack_sign_bits(torch.rand((a.n_cols, w), device=dev) - 0.75)    # a quarter of the bits set
+            tmp = torch.empty((a.n_cols, w), device=dev)
+
+            def two():
+                ops.gemm(d, w2, trans_b=True, out=tmp, gate_bits=bits, gate_scale=2.0)
+                ops.spmm(a, tmp, out=out)
+
+            def one():
+                ops.spmm_factored(a, d, w2, bits, gate_scale=2.0, trans_w=True, out=out)
+            for name, fn in (("bit-gated product + SpMM", two), ("factored SpMM", one)):
+                fn()
+                torch.cuda.synchronize()
+                ev[0].record()
+                for i in range(args.iters):
+                    fn()
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
+                print("W=%d %s: %.3f ms (min %.3f)" % (w, name, ms[len(ms) // 2], ms[0]), flush=True)
+            del d, w2, bits, tmp
         del b, out
 
 
