@@ -277,8 +277,11 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
 // against weights held in registers -- 96 bytes fetched per nonzero instead of a
 // 1-KiB row, paid for with vector arithmetic the memory-bound kernel has to
 // spare.  The sum over k is a chain of fused multiply-adds from zero in the
-// order in which the two-kernel path feeds k to its matrix instruction, so both
-// paths give the same bits.
+// order in which the two-kernel path feeds k to its matrix instruction; the gate
+// scale multiplies the matrix value instead of the element, so both paths give
+// the same bits when the scale is a power of two (dropout 0.5) and differ by one
+// rounding per term otherwise.  This is the fallback of spmm_factored_mfma_kernel
+// for operands whose pitch rules out 16-byte loads.
 constexpr int kFactoredInner = 16;
 typedef float __attribute__((ext_vector_type(16))) f16s;
 typedef const f16s __attribute__((address_space(4))) *const_f16s_ptr;
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_kernel(const SpmmArgs
         if (j + u < jn) {
           const int k = kb + j + u;
           while (k == re) close_row();
-          const float v = rl_f(vals, j + u);
+          const float v = rl_f(vals, j + u) * a.fscale;   // the gate scale rides on the matrix value
           V t = V(0.0f);
 #pragma unroll
           for (int q = 0; q < kFactoredInner; ++q) {
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_kernel(const SpmmArgs
           const uint32_t bits = gw[u] >> shift;
           V g;
 #pragma unroll
-          for (int jx = 0; jx < 4; ++jx) g[jx] = ((bits >> jx) & 1u) ? t[jx] * a.fscale : 0.0f;
+          for (int jx = 0; jx < 4; ++jx) g[jx] = ((bits >> jx) & 1u) ? t[jx] : 0.0f;
           acc += g * v;
         }
       }
@@ -400,6 +403,207 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_kernel(const SpmmArgs
   }
   while (re <= nk) close_row();
   if (r < a.n_rows && rs < nk && active) vstore<4>(pslot + (rs < 0 ? 0 : a.pwidth), acc);
+}
+
+// The factored product with the row-forming on the matrix pipe.  The two halves
+// of a wavefront each own one chunk.  Per round each half contributes 16 of its
+// nonzeros as rows of a 32 x 16 A operand (their D rows); eight chains of
+// v_mfma_f32_32x32x2_f32 against the weights give T = D_rows * W for 32 nonzeros
+// x 256 columns.  In the C/D layout a lane holds one column per tile and, in its
+// 16 registers, the 16 nonzeros of ITS half in order (MFMA row i belongs to half
+// (i >> 2) & 1 and is that half's nonzero (i & 3) + 4 (i >> 3)), so each half
+// then walks its nonzeros exactly as the wide kernel does -- gate, scale by the
+// matrix value, add to the open row, close rows at their ends -- with per-half
+// (divergent) row bookkeeping.  The k order of the chains is the one of
+// gemm_small_k_mfma_kernel and rows are summed chunk-sequentially; the gate scale
+// multiplies the matrix value instead of the element, so the result has the bits
+// of the two-kernel path when the scale is a power of two (dropout 0.5) and
+// differs from it by one rounding per term otherwise.
+typedef float __attribute__((ext_vector_type(16))) f16acc;
+typedef uint32_t __attribute__((ext_vector_type(4))) u4v;
+
+template <int NT>            // 32-column tiles per wavefront: a slab of 32 NT columns per blockIdx.y
+__global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const SpmmArgs a) {
+  constexpr int HW = 32;     // lanes per half
+  const int lane = threadIdx.x & (kWave - 1);
+  const int li = lane & 31, h = lane >> 5;
+  const int wid = (int)(threadIdx.x >> 6);
+  const int64_t ch = 2 * ((int64_t)blockIdx.x * kWavesPerBlock + wid) + h;
+  const bool live = ch < a.n_chunks;
+  const int cbase = (int)blockIdx.y * (NT * 32);
+  const int nt = (a.width - cbase) / 32 < NT ? (a.width - cbase) / 32 : NT;
+
+  // op(W) fragments: B[k][j] of tile t, k fed in the order of gemm_small_k_mfma_kernel
+  float bf[NT][8];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int sx = 0; sx < 8; ++sx) {
+      const int k = 8 * (sx >> 2) + 4 * h + (sx & 3);
+      bf[t][sx] = t < nt ? a.Wm[k * a.w_sk + (int64_t)(cbase + 32 * t + li) * a.w_sj] : 0.0f;
+    }
+
+  const int chunk = a.chunk;
+  const int64_t n0 = live ? ch * (int64_t)chunk : 0;
+  int nk = 0;
+  if (live) {
+    const int64_t left = a.nnz - n0;
+    nk = left < (int64_t)chunk ? (int)left : chunk;
+  }
+  const int nk_other = __shfl_xor(nk, HW, kWave);
+  const int nk_max = nk > nk_other ? nk : nk_other;
+
+  int64_t r = live ? (int64_t)a.chunk_row[ch * a.chunk_mul] : a.n_rows;
+  int64_t rbase = r;
+  // half-held window: lane li holds the end (relative to n0) of row rbase + li
+  auto load_row_ends = [&](int64_t rb) -> int {
+    const int64_t rr = rb + 1 + li;
+    if (rr > a.n_rows) return kRowEndBeyond;
+    const int64_t e = a.row_ptr[rr] - n0;
+    return e > (int64_t)chunk ? chunk + 1 : (int)e;
+  };
+  int re_v = load_row_ends(rbase);
+  int re = __shfl(re_v, h * HW, kWave);
+  int rs = -1;
+  if (live && r < a.n_rows) {
+    const int64_t s0 = a.row_ptr[r] - n0;
+    rs = s0 < 0 ? -1 : (int)s0;
+  }
+  float acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
+  float *const pslot = a.partial + (size_t)(live ? ch : 0) * 2 * a.pwidth + cbase + li;
+
+  auto close_row = [&]() {
+    float *dst = rs < 0 ? pslot : a.C + r * a.ldc + cbase + li;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) dst[32 * t] = acc[t];
+      acc[t] = 0.0f;
+    }
+    rs = re;
+    ++r;
+    int idx = (int)(r - rbase);
+    if (idx == HW) {
+      rbase = r;
+      re_v = load_row_ends(rbase);
+      idx = 0;
+    }
+    re = __shfl(re_v, h * HW + idx, kWave);
+  };
+
+  // MFMA row i = li of the A operand is nonzero an of half ah
+  const int ah = (li >> 2) & 1, an = (li & 3) + 4 * (li >> 3);
+
+  for (int kb = 0; kb < nk_max; kb += HW) {
+    int cols = 0;
+    float vals = 0.0f;
+    if (kb + li < nk) {
+      cols = a.col_idx[n0 + kb + li];
+      // the gate scale rides on the matrix value (one multiplication per nonzero
+      // instead of one per element)
+      vals = a.val[n0 + kb + li] * a.fscale;
+    }
+#pragma unroll 1
+    for (int sb = 0; sb < 2; ++sb) {
+      const int k0 = kb + 16 * sb;
+      if (k0 >= nk_max) break;
+      // A fragments: D row of nonzero (ah, an) of this round, k = 4 h .. and 8 + 4 h ..
+      float af[8];
+      {
+        const int cc = __shfl(cols, ah * HW + 16 * sb + an, kWave);
+        const float *drow = cc < a.split ? a.D + (int64_t)cc * a.ldd : a.D2 + (int64_t)(cc - a.split) * a.ldd2;
+        const typename vec_of<4>::type a0 = vload<4>(drow + 4 * h), a1 = vload<4>(drow + 8 + 4 * h);
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) { af[jx] = a0[jx]; af[4 + jx] = a1[jx]; }
+      }
+      // gate words of this half's 16 nonzeros: lane li holds words 4 g .. 4 g + 3
+      // (g = li >> 4) of the slab's words of nonzero li & 15; a nonzero past the
+      // end of the chunk gets zero words, i.e. contributes an exact zero
+      u4v wq = u4v(0u);
+      {
+        const int cw = __shfl(cols, h * HW + 16 * sb + (li & 15), kWave);
+        const int g = li >> 4;
+        if (4 * g < nt && k0 + (li & 15) < nk) {
+          const uint32_t *grow = cw < a.split ? a.gbits + (int64_t)cw * a.ldgb
+                                              : a.gbits2 + (int64_t)(cw - a.split) * a.ldgb2;
+          wq = *reinterpret_cast<const u4v *>(grow + (cbase >> 5) + 4 * g);
+        }
+      }
+      f16acc T[NT];
+      // the wavefront that is on the matrix pipe goes first: resident wavefronts
+      // would otherwise share the pipe evenly, stay in step and never overlap
+      // one's matrix phase with the other's vector phase
+      __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[t][i] = 0.0f;
+        if (t < nt) {
+#pragma unroll
+          for (int sx = 0; sx < 8; ++sx) T[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sx], bf[t][sx], T[t], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        const int k = k0 + n;
+        // row bookkeeping is per half (divergent); the arithmetic below is not.
+        // (Past the end of a chunk k can only meet a row end that lies exactly on
+        // the chunk end, which the loop after the rounds would close anyway.)
+        while (k == re) close_row();
+        const int src = 16 * sb + n;
+        const float v_lo = rl_f(vals, src), v_hi = rl_f(vals, HW + src);
+        const float vs = h ? v_hi : v_lo;
+        // The two halves' gate words of a tile, side by side, ARE the lane mask of
+        // that tile's update (bit li of the low word gates lane li, of the high
+        // word lane 32 + li): the multiply-add runs under that mask as EXEC.
+        uint64_t mask[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int wl = n + 16 * (t >> 2);
+          const uint32_t m_lo = (uint32_t)rl_i((int)wq[t & 3], wl), m_hi = (uint32_t)rl_i((int)wq[t & 3], HW + wl);
+          mask[t] = ((uint64_t)m_hi << 32) | m_lo;
+        }
+        if constexpr (NT == 8) {
+          asm volatile(
+              "s_mov_b64 exec, %16\n\tv_fmac_f32 %0, %8, %24\n\t"
+              "s_mov_b64 exec, %17\n\tv_fmac_f32 %1, %9, %24\n\t"
+              "s_mov_b64 exec, %18\n\tv_fmac_f32 %2, %10, %24\n\t"
+              "s_mov_b64 exec, %19\n\tv_fmac_f32 %3, %11, %24\n\t"
+              "s_mov_b64 exec, %20\n\tv_fmac_f32 %4, %12, %24\n\t"
+              "s_mov_b64 exec, %21\n\tv_fmac_f32 %5, %13, %24\n\t"
+              "s_mov_b64 exec, %22\n\tv_fmac_f32 %6, %14, %24\n\t"
+              "s_mov_b64 exec, %23\n\tv_fmac_f32 %7, %15, %24\n\t"
+              "s_mov_b64 exec, -1"
+              : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                "+v"(acc[7])
+              : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "v"(T[4][n]), "v"(T[5][n]), "v"(T[6][n]),
+                "v"(T[7][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4]), "s"(mask[5]),
+                "s"(mask[6]), "s"(mask[7]), "v"(vs));
+        } else {
+          asm volatile(
+              "s_mov_b64 exec, %8\n\tv_fmac_f32 %0, %4, %12\n\t"
+              "s_mov_b64 exec, %9\n\tv_fmac_f32 %1, %5, %12\n\t"
+              "s_mov_b64 exec, %10\n\tv_fmac_f32 %2, %6, %12\n\t"
+              "s_mov_b64 exec, %11\n\tv_fmac_f32 %3, %7, %12\n\t"
+              "s_mov_b64 exec, -1"
+              : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+              : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]),
+                "s"(mask[3]), "v"(vs));
+        }
+      }
+    }
+  }
+  if (live) {
+    while (re <= nk) close_row();
+    if (r < a.n_rows && rs < nk) {
+      float *dst = pslot + (rs < 0 ? 0 : a.pwidth);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt) dst[32 * t] = acc[t];
+    }
+  }
 }
 
 // Narrow dense operands (at most 32 lanes wide): the wavefront is cut into
@@ -997,7 +1201,22 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
   const unsigned gx = (unsigned)ceil_div(k.n_chunks, kWavesPerBlock);
   const unsigned gy = (unsigned)ceil_div(width, kWave * 4);
   if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
-  hipLaunchKernelGGL((spmm_factored_kernel<GCNX_FACTORED_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+  // row-forming on the matrix pipe when the operands allow 16-byte loads
+  const bool mfma_ok = (ldd % 4 == 0) && aligned16(D) && (ld_words % 4 == 0) && aligned16(gate_bits) &&
+                       (k.split == INT32_MAX || ((ldd2 % 4 == 0) && aligned16(D2) && (ld_words2 % 4 == 0) &&
+                                                 aligned16(gate_bits2)));
+  if (mfma_ok) {
+    // two chunks per wavefront; 256-column slabs (8 accumulator tiles) when the
+    // width fills them, 128-column slabs otherwise
+    const int64_t pairs = ceil_div(k.n_chunks, 2);
+    const unsigned gxp = (unsigned)ceil_div(pairs, kWavesPerBlock);
+    if (width % 256 == 0 || width > 512)
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8>), dim3(gxp, (unsigned)ceil_div(width, 256)), dim3(kBlock), 0, st, k);
+    else
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4>), dim3(gxp, (unsigned)ceil_div(width, 128)), dim3(kBlock), 0, st, k);
+  } else {
+    hipLaunchKernelGGL((spmm_factored_kernel<GCNX_FACTORED_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+  }
   GCNX_CHECK_LAUNCH();
   if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
   if (k.n_chunks > 1) {
@@ -1006,3 +1225,4 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
   }
   return GCNX_OK;
 }
+

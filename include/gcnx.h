@@ -183,9 +183,13 @@ int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row,
  * c - split_col): the halo rows received from peers.  This is the backward
  * pass  A_hat^T * ((H' > 0) ? (dP2 * W2^T) / keep : 0)  in one kernel: 96 bytes
  * fetched per nonzero instead of a 1-KiB row of a stored intermediate, and the
- * gated product (gcnx_gemm_bitgated_f32) is not run at all.  The k-sum is an
- * ascending chain of fused multiply-adds from zero, as in the two-kernel path,
- * so both give the same bits.  Served for inner == 16, width >= 64,
+ * gated product (gcnx_gemm_bitgated_f32) is not run at all.  The k-sum is the
+ * chain of fused multiply-adds of the two-kernel path and rows are summed in the
+ * same order; gate_scale multiplies the matrix value rather than the element,
+ * so both give the same bits when gate_scale is a power of two and agree to one
+ * rounding per term otherwise.  With 16-byte aligned D / gate words (ldd and
+ * ld_words multiples of 4) the rows are formed on the matrix pipe, two chunks
+ * per wavefront.  Served for inner == 16, width >= 64,
  * width % 32 == 0 (gcnx_spmm_factored_supported); workspace as for
  * gcnx_spmm_csr_f32 at this width.
  * replaces: the gradient of tf.sparse_tensor_dense_matmul composed with the

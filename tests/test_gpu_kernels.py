@@ -748,6 +748,34 @@ def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
     assert_close_to_f64(got.cpu().numpy(), m @ g64, abs(m) @ gmag, what="factored spmm")
 
 
+def test_spmm_factored_paths_and_general_scale(env):
+    """Rows of D with a pitch that rules out 16-byte loads take the vector-ALU
+    form of the kernel; a gate scale that is not a power of two multiplies the
+    matrix value instead of the element (one rounding apart from the two-kernel
+    path, inside the fp32 bar)."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(77)
+    n, width = 2500, 256
+    rows, cols, vals = random_coo(rng, n, n, 60000, hub_rows=((3, 2000),), empty_rows=(5,))
+    a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n), device=dev)
+    wide = torch.from_numpy(rng.standard_normal((n, 17)).astype(np.float32)).to(dev)
+    d_odd = wide[:, :16]                                    # pitch 17 floats
+    d = d_odd.contiguous()
+    w = torch.from_numpy((rng.standard_normal((width, 16)) * 0.3).astype(np.float32)).to(dev)
+    bits = ops.pack_sign_bits(torch.from_numpy(rng.standard_normal((n, width)).astype(np.float32)).to(dev))
+    fast = ops.spmm_factored(a, d, w, bits, gate_scale=2.0, trans_w=True)
+    slow = ops.spmm_factored(a, d_odd, w, bits, gate_scale=2.0, trans_w=True)
+    assert torch.equal(fast, slow)
+    for scale in (1.0 / 0.9, 3.0):
+        want = ops.spmm(a, ops.gemm(d, w, trans_b=True, gate_bits=bits, gate_scale=scale))
+        mag = ops.spmm(Csr(a.n_rows, a.n_cols, a.row_ptr, a.col_idx, a.val.abs()),
+                       ops.gemm(d.abs(), w.abs(), trans_b=True, gate_bits=bits, gate_scale=scale))
+        for dd in (d, d_odd):
+            got = ops.spmm_factored(a, dd, w, bits, gate_scale=scale, trans_w=True)
+            assert bool(((got - want).abs() <= 1e-6 * mag + 1e-30).all())
+
+
 def test_spmm_factored_rejects_unsupported(env):
     torch, ops, dev = env["torch"], env["ops"], env["dev"]
     assert not ops.spmm_supports_factored(256, 8)
