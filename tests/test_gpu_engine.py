@@ -61,6 +61,9 @@ def _dense_tuple(x):
 
 @pytest.mark.parametrize("hidden,classes,order,scale,f", [
     (16, 7, "reference", 9, 48), (128, 16, "reference", 9, 48),
+    # the benchmark's widths: sign words out of the forward SpMM, backward SpMM with
+    # the factored operand (rows of d(A P1) formed per nonzero), MFMA products
+    (256, 16, "reference", 11, 128),
     # (A_hat X') W1: the same sums associated the other way (the oracle keeps the
     # reference order); the second case runs the fused relu + dropout epilogue
     (16, 7, "aggregate_first", 9, 48), (128, 16, "aggregate_first", 11, 64)])
@@ -82,6 +85,7 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
     sup = (np.stack([rows, ci], 1), v, (n, n))
     orc = omodel.TwoLayerOracle("gcn", _dense_tuple(x), [sup], [[w1], [w2]], lr=0.01, weight_decay=5e-4)
+    unclear = {}
     for step in (1, 2, 3):
         off = step * (1 << 44)
         m1 = env["oracle"].bernoulli_mask(n * f, 0.5, 123 * 2 + 1, off)
@@ -89,16 +93,28 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
         logits, cache = orc.forward(m1, m2, 0.5)
         xent, grad = env["oracle"].masked_softmax_xent(logits, labels, lmask)
         acc = env["oracle"].masked_accuracy(logits, labels, lmask)
-        orc.adam(orc.backward(cache, grad))
+        grads = orc.backward(cache, grad)
+        g_ref = [grads[0][0] - np.float32(5e-4) * orc.w[0][0], grads[1][0]]    # without the weight-decay term
+        orc.adam(grads)
         got = eng.train_step().cpu().numpy()
+        for g_gpu, g_want in zip((eng.g1, eng.g2), g_ref):
+            assert np.abs(g_gpu.cpu().numpy() - g_want).max() <= 2e-5 * np.abs(g_want).max()
         assert abs(got[0] - xent) <= 1e-5 * abs(xent) + 1e-6, (step, got[0], xent)
         assert abs(got[1] - acc) <= 1e-6
         assert np.abs(eng.z.cpu().numpy() - logits).max() <= 2e-5 * np.abs(logits).max()
         # an Adam step moves every weight by about lr whatever the gradient's size, so
         # with the other association a near-zero gradient may round the other way
         wtol = 2e-6 if order == "reference" else 2e-4
-        for w_gpu, w_ref in ((eng.w1, orc.w[0][0]), (eng.w2, orc.w[1][0])):
-            assert np.abs(w_gpu.cpu().numpy() - w_ref).max() <= 1e-5 * np.abs(w_ref).max() + wtol
+        for w_gpu, w_ref, g_want in ((eng.w1, orc.w[0][0], grads[0][0]), (eng.w2, orc.w[1][0], grads[1][0])):
+            err = np.abs(w_gpu.cpu().numpy() - w_ref)
+            # entries whose gradient is within rounding of zero may step the other
+            # way (by up to 2 lr per step); they are bounded, the rest is compared
+            key = id(w_gpu)
+            unclear[key] = unclear.get(key, False) | (np.abs(g_want) <= 1e-3 * np.abs(g_want).max())
+            clear = ~unclear[key]
+            assert clear.mean() > 0.9
+            assert err[clear].max() <= 1e-5 * np.abs(w_ref).max() + wtol
+            assert err.max() <= 2 * 0.01 * step + 1e-6
     ev = eng.evaluate().cpu().numpy()
     logits, _ = orc.forward()
     xent, _ = env["oracle"].masked_softmax_xent(logits, labels, lmask, want_grad=False)
