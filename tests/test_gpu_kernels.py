@@ -703,7 +703,9 @@ def test_degenerate_sizes_are_no_ops(env):
 
 
 @pytest.mark.parametrize("n,nnz,width,halo", [(3000, 40000, 256, 0), (5000, 90000, 128, 700), (900, 9000, 64, 0),
-                                               (4000, 200000, 512, 1500)])
+                                               (4000, 200000, 512, 1500),
+                                               # fewer nonzeros than one round / one chunk; an odd number of chunks
+                                               (40, 30, 256, 0), (300, 9, 256, 5), (2000, 64 * 3 + 1, 256, 0)])
 def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
     """A @ gate(D W^T) with the operand formed per nonzero against the stored
     intermediate (bit-gated product, then SpMM): same bits; and against the
@@ -712,7 +714,7 @@ def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
     from gcn_amd.sparse import Csr
     rng = np.random.RandomState(n + width)
     n_cols = n + halo
-    rows, cols, vals = random_coo(rng, n, n_cols, nnz, hub_rows=((7, 3000),), empty_rows=(0, 11, n - 1))
+    rows, cols, vals = random_coo(rng, n, n_cols, nnz, hub_rows=((7, min(3000, nnz // 3)),), empty_rows=(0, 11, n - 1))
     a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n_cols), device=dev)
     d = torch.from_numpy(rng.standard_normal((n_cols, 16)).astype(np.float32)).to(dev)
     w = torch.from_numpy((rng.standard_normal((width, 16)) * 0.3).astype(np.float32)).to(dev)     # W2 [hidden, classes]
@@ -726,11 +728,12 @@ def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
                                 d2=d[n:].contiguous(), gate_bits2=bits[n:].contiguous())
     else:
         got = ops.spmm_factored(a, d, w, bits, gate_scale=2.0, trans_w=True)
-    if width > 128:
+    if width > 128 and n_cols >= 1024:
         assert torch.equal(got, want)      # both walk a row's nonzeros in order, lane-private sums
     else:
-        # at these widths the plain SpMM splits a row's nonzeros over lane groups
-        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # at narrow widths the plain SpMM splits a row's nonzeros over lane groups, and
+        # a product with few rows is served by the register-tiled kernel (other k order)
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-30
     # W given as [inner, width]
     got2 = ops.spmm_factored(a, d[:n].contiguous(), w.t().contiguous(), bits[:n].contiguous(), gate_scale=2.0,
                              d2=d[n:].contiguous() if halo else None,
