@@ -680,7 +680,12 @@ __global__ __launch_bounds__(kBlock) void spmm_slot_kernel(const SpmmArgs a) {
       if (rs < 0) {
         vstore<VEC>(pslot, tot);
       } else {
-        epilogue_store<VEC>(a, r, col0, tot);
+        const V out = epilogue_store<VEC>(a, r, col0, tot);
+        if constexpr (VEC == 4 && LW >= 8) {
+          // whole groups of 8 lanes are active (the host admits sign words only
+          // for widths that are multiples of 32)
+          if (a.sign_bits) store_sign_word(a, r, col0, lane, out);
+        }
       }
     }
     acc = V(0.0f);
@@ -965,7 +970,7 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
                    mask_scale, fuse_relu, out_dropout, nullptr, 0, ws, ws_bytes, stream);
 }
 
-extern "C" int gcnx_spmm_signs_supported(int32_t width) { return (width > 128 && width % 32 == 0) ? 1 : 0; }
+extern "C" int gcnx_spmm_signs_supported(int32_t width) { return (width >= 32 && width % 32 == 0) ? 1 : 0; }
 
 extern "C" int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
                                        int64_t ldb, const float *B2, int64_t ldb2, int64_t split_col,
@@ -974,7 +979,7 @@ extern "C" int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_r
                                        uint32_t *sign_bits, int64_t ld_words, void *ws, size_t ws_bytes,
                                        void *stream) {
   GCNX_REQUIRE(sign_bits && ld_words * 32 >= width && gcnx_spmm_signs_supported(width), GCNX_ERR_UNSUPPORTED,
-               "spmm_signs: needs width > 128, width %% 32 == 0 and ld_words * 32 >= width");
+               "spmm_signs: needs width %% 32 == 0 and ld_words * 32 >= width");
   return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, nullptr, nullptr,
                    1.0f, fuse_relu, out_dropout, sign_bits, ld_words, ws, ws_bytes, stream);
 }
@@ -1067,7 +1072,7 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   const int lanes = (width + vec - 1) / vec;      // lanes one row of B needs
   unsigned gy = 1;
   if (g_prof_start) GCNX_CHECK_HIP(hipEventRecord(g_prof_start, st));
-  if (lanes <= 32 && a->nnz <= g_row_path_max_nnz.load() && a->nnz <= kRowPathMaxAvg * a->n_rows) {
+  if (!sign_bits && lanes <= 32 && a->nnz <= g_row_path_max_nnz.load() && a->nnz <= kRowPathMaxAvg * a->n_rows) {
     const unsigned gr = (unsigned)ceil_div(a->n_rows, kWavesPerBlock);
 #define GCNX_ROW(V, L) hipLaunchKernelGGL((spmm_row_kernel<V, L>), dim3(gr), dim3(kBlock), 0, st, k)
     if (v4) {
@@ -1094,7 +1099,7 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
 #define GCNX_SLOT_U 4       // gather groups in flight per wavefront in the narrow kernel
 #endif
 #define GCNX_SLOT(V, L) hipLaunchKernelGGL((spmm_slot_kernel<V, L, GCNX_SLOT_U>), dim3(gx), dim3(kBlock), 0, st, k)
-  GCNX_REQUIRE(!sign_bits || (v4 && lanes > 32), GCNX_ERR_UNSUPPORTED,
+  GCNX_REQUIRE(!sign_bits || (v4 && width % 32 == 0), GCNX_ERR_UNSUPPORTED,
                "spmm_signs: operands must be 16-byte aligned with rows that are multiples of 4 floats");
   if (lanes > 32) {
     gy = (unsigned)ceil_div(lanes, kWave);

@@ -161,8 +161,8 @@ int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row,
  * bit (c % 32) of sign_bits[r * ld_words + c / 32] is set iff stored element
  * (r, c) > 0 (after activation and dropout).  With the relu + dropout epilogue
  * this is the whole gate the backward pass needs (gcnx_gemm_bitgated_f32), 32
- * bytes per 256-wide row instead of re-reading the 1-KiB row.  Wide operands
- * only (width > 128, width % 32 == 0: gcnx_spmm_signs_supported); no value mask.
+ * bytes per 256-wide row instead of re-reading the 1-KiB row.  Widths that are
+ * multiples of 32 (gcnx_spmm_signs_supported), 16-byte aligned operands; no value mask.
  * replaces: the relu and dropout gradients of gcn/layers.py:226,210 created at
  * gcn/models.py:58 (their masks). */
 int gcnx_spmm_signs_supported(int32_t width);

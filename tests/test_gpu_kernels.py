@@ -624,7 +624,10 @@ def test_cabi_client_without_python(spmm_path):
 
 
 @pytest.mark.parametrize("n,nnz,width,split", [(3000, 40000, 256, False), (2000, 30000, 160, True),
-                                               (900, 200000, 512, False)])
+                                               (900, 200000, 512, False),
+                                               # the narrow kernel (lane groups per row)
+                                               (2500, 50000, 128, True), (3000, 30000, 64, False),
+                                               (1200, 20000, 32, False), (1500, 25000, 96, False)])
 def test_spmm_sign_bits(env, n, nnz, width, split):
     """The sign pattern written by the SpMM epilogue == pack_sign_bits of the
     stored output, and the stored output is that of the plain call."""
@@ -643,8 +646,13 @@ def test_spmm_sign_bits(env, n, nnz, width, split):
     plain = env["ops"].spmm(a, b1, **kw)
     bits = torch.full((n, width // 32), -1, dtype=torch.int32, device=dev)
     got = env["ops"].spmm(a, b1, sign_bits=bits, **kw)
-    assert torch.equal(plain, got)
-    assert torch.equal(bits, env["ops"].pack_sign_bits(plain))
+    if width > 128:
+        assert torch.equal(plain, got)
+    else:
+        # a small matrix with a narrow operand takes the wavefront-per-row kernel
+        # in the plain call and the chunk walk when sign words are asked for
+        assert float((plain - got).abs().max()) <= 1e-5 * float(plain.abs().max())
+    assert torch.equal(bits, env["ops"].pack_sign_bits(got))
 
 
 @pytest.mark.parametrize("M,N", [(5, 3), (4096, 256), (700, 64)])
