@@ -71,7 +71,7 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
         if mask is not None or sb.dtype != torch.int32 or sb.dim() != 2 or sb.shape[0] != a.n_rows or \
                 sb.shape[1] * 32 < width or sb.stride(1) != 1 or sb.device != a.device or \
                 not spmm_supports_sign_bits(width):
-            raise ValueError("sign_bits: int32 [n_rows, width / 32] on A's device, width > 128, width % 32 == 0, no mask")
+            raise ValueError("sign_bits: int32 [n_rows, width / 32] on A's device, width % 32 == 0, no mask")
         with torch.cuda.device(a.device):
             need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
             ws = WORKSPACE.get(need, a.device)
