@@ -422,7 +422,9 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_kernel(const SpmmArgs
 typedef float __attribute__((ext_vector_type(16))) f16acc;
 typedef uint32_t __attribute__((ext_vector_type(4))) u4v;
 
-template <int NT>            // 32-column tiles per wavefront: a slab of 32 NT columns per blockIdx.y
+// NT: 32-column tiles per wavefront (a slab of 32 NT columns per blockIdx.y);
+// FULL: the width is a multiple of the slab, no tile needs a bounds check.
+template <int NT, bool FULL>
 __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const SpmmArgs a) {
   constexpr int HW = 32;     // lanes per half
   const int lane = threadIdx.x & (kWave - 1);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
   const int64_t ch = 2 * ((int64_t)blockIdx.x * kWavesPerBlock + wid) + h;
   const bool live = ch < a.n_chunks;
   const int cbase = (int)blockIdx.y * (NT * 32);
-  const int nt = (a.width - cbase) / 32 < NT ? (a.width - cbase) / 32 : NT;
+  const int nt = FULL ? NT : ((a.width - cbase) / 32 < NT ? (a.width - cbase) / 32 : NT);
 
   // op(W) fragments: B[k][j] of tile t, k fed in the order of gemm_small_k_mfma_kernel
   float bf[NT][8];
@@ -474,8 +476,9 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
   for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
   float *const pslot = a.partial + (size_t)(live ? ch : 0) * 2 * a.pwidth + cbase + li;
 
+  float *crow = a.C + r * a.ldc + cbase + li;   // this lane's first column of row r
   auto close_row = [&]() {
-    float *dst = rs < 0 ? pslot : a.C + r * a.ldc + cbase + li;
+    float *dst = rs < 0 ? pslot : crow;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) dst[32 * t] = acc[t];
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
     }
     rs = re;
     ++r;
+    crow += a.ldc;
     int idx = (int)(r - rbase);
     if (idx == HW) {
       rbase = r;
@@ -1215,10 +1219,14 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
     // width fills them, 128-column slabs otherwise
     const int64_t pairs = ceil_div(k.n_chunks, 2);
     const unsigned gxp = (unsigned)ceil_div(pairs, kWavesPerBlock);
-    if (width % 256 == 0 || width > 512)
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8>), dim3(gxp, (unsigned)ceil_div(width, 256)), dim3(kBlock), 0, st, k);
+    if (width % 256 == 0)
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8, true>), dim3(gxp, (unsigned)(width / 256)), dim3(kBlock), 0, st, k);
+    else if (width > 512)
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8, false>), dim3(gxp, (unsigned)ceil_div(width, 256)), dim3(kBlock), 0, st, k);
+    else if (width % 128 == 0)
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4, true>), dim3(gxp, (unsigned)(width / 128)), dim3(kBlock), 0, st, k);
     else
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4>), dim3(gxp, (unsigned)ceil_div(width, 128)), dim3(kBlock), 0, st, k);
+      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4, false>), dim3(gxp, (unsigned)ceil_div(width, 128)), dim3(kBlock), 0, st, k);
   } else {
     hipLaunchKernelGGL((spmm_factored_kernel<GCNX_FACTORED_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
   }

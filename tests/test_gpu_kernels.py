@@ -711,7 +711,7 @@ def test_degenerate_sizes_are_no_ops(env):
 
 
 @pytest.mark.parametrize("n,nnz,width,halo", [(3000, 40000, 256, 0), (5000, 90000, 128, 700), (900, 9000, 64, 0),
-                                               (4000, 200000, 512, 1500),
+                                               (4000, 200000, 512, 1500), (1500, 30000, 640, 0),
                                                # fewer nonzeros than one round / one chunk; an odd number of chunks
                                                (40, 30, 256, 0), (300, 9, 256, 5), (2000, 64 * 3 + 1, 256, 0)])
 def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
