@@ -557,8 +557,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
         // the chunk end, which the loop after the rounds would close anyway.)
         while (k == re) close_row();
         const int src = 16 * sb + n;
-        const float v_lo = rl_f(vals, src), v_hi = rl_f(vals, HW + src);
-        const float vs = h ? v_hi : v_lo;
+        const float vs = __shfl(vals, h * HW + src, kWave);   // the half's own nonzero (LDS crossbar, no vector-ALU slot)
         // The two halves' gate words of a tile, side by side, ARE the lane mask of
         // that tile's update (bit li of the low word gates lane li, of the high
         // word lane 32 + li): the multiply-add runs under that mask as EXEC.
