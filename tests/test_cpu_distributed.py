@@ -33,11 +33,12 @@ def _problem(scale=7, f=12, hidden=16, classes=5):
     return n, a_hat, x, w1, w2, labels, lmask, hidden, classes
 
 
-def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5):
+def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5,
+         classes=5):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(hidden=hidden)
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(hidden=hidden, classes=classes)
     n_loc = n // world
     rb, re_ = rank * n_loc, (rank + 1) * n_loc
     T = torch.from_numpy
@@ -48,6 +49,10 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
         kernels=OracleKernels(), halo_mode=halo_mode, order=order, dropout=dropout)
     if world > 1:
         assert eng.recompute == (halo_mode == "recompute" and order == "reference")
+    # 16 classes and a hidden width that is a multiple of 64: the backward product
+    # with the factored operand (dP2 rows + sign words, local and halo)
+    assert eng.factored_bwd == (classes == 16 and hidden % 64 == 0 and order == "reference" and
+                                (world == 1 or eng.recompute))
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
     ev = eng.evaluate().numpy().copy()
     np.savez(os.path.join(out_dir, "w%d_r%d%s.npz" % (world, rank, tag)), outs=np.stack(outs), ev=ev,
@@ -65,14 +70,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,slab,halo_mode,hidden", [
-    (2, 16, "exchange", 16), (2, 8, "exchange", 16), (4, 4, "exchange", 16),
+@pytest.mark.parametrize("world,slab,halo_mode,hidden,classes", [
+    (2, 16, "exchange", 16, 5), (2, 8, "exchange", 16, 5), (4, 4, "exchange", 16, 5),
     # halo rows of the hidden-width products recomputed by the GPU that needs them
-    (2, 16, "recompute", 32), (4, 8, "recompute", 64)])
-def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden):
+    (2, 16, "recompute", 32, 5), (4, 8, "recompute", 64, 5),
+    # ... and the backward SpMM with the factored operand over local + halo rows
+    (2, 16, "recompute", 64, 16)])
+def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden, classes):
     out = str(tmp_path)
-    _run(0, 1, 0, None, out, "auto", hidden)
-    mp.spawn(_run, args=(world, _free_port(), slab, out, halo_mode, hidden), nprocs=world, join=True)
+    _run(0, 1, 0, None, out, "auto", hidden, classes=classes)
+    mp.spawn(_run, args=(world, _free_port(), slab, out, halo_mode, hidden, "reference", "", 0.5, classes),
+             nprocs=world, join=True)
     one = np.load(os.path.join(out, "w1_r0.npz"))
     r0 = np.load(os.path.join(out, "w%d_r0.npz" % world))
     r1 = np.load(os.path.join(out, "w%d_r1.npz" % world))
