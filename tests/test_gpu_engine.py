@@ -161,6 +161,16 @@ def test_spmm_properties_at_scale(env, scale):
     rhs = 2 * out + env["ops"].spmm(a, c)
     assert float((lhs - rhs).abs().max()) <= 1e-4
     del lhs, rhs, c, out2
+    # the factored operand (rows formed per nonzero from 16-wide rows and sign
+    # words) against the stored intermediate: same bits at full size, hub rows included
+    d = torch.rand((n, 16), device=dev, generator=g) - 0.5
+    w2 = torch.rand((256, 16), device=dev, generator=g) - 0.5
+    bits = env["ops"].pack_sign_bits(b)
+    stored = env["ops"].gemm(d, w2, trans_b=True, gate_bits=bits, gate_scale=2.0, out=b)   # b is free now
+    want = env["ops"].spmm(a, stored, out=out)
+    got = env["ops"].spmm_factored(a, d, w2, bits, gate_scale=2.0, trans_w=True)
+    assert torch.equal(got, want)
+    del got, want, stored, d, bits
     # transpose of a symmetric matrix reproduces it bit for bit
     t = a.transpose()
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)
