@@ -73,6 +73,8 @@ SIGNATURES = {
     "gcnx_gemm_relu_dropout_supported": (_int, [_int, _int, _i64, _i64, _i64]),
     "gcnx_gemm_relu_dropout_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _f32,
                                           _f32, _int, _p, _p, _sz, _p]),
+    "gcnx_gemm_relu_dropout_signs_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _f32,
+                                                _f32, _int, _p, _p, _i64, _p, _sz, _p]),
     "gcnx_gemm_bitgated_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _f32,
                                       _f32, _p, _i64, _f32, _p, _sz, _p]),
     "gcnx_pack_sign_bits_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),

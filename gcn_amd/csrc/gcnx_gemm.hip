@@ -58,6 +58,10 @@ struct GemmArgs {
   int64_t odrop_ld;
   int64_t odrop_col0;
   int odrop_vec;   // the 16-byte epilogue of the MFMA kernel may be used
+  // nullable, with the output dropout only: sign pattern of the stored C, bit
+  // (n % 32) of osign[m * ld_osign + n / 32] set <=> stored element (m, n) > 0
+  uint32_t *osign;
+  int64_t ld_osign;
 };
 
 typedef float __attribute__((ext_vector_type(4))) f4v;
@@ -221,6 +225,16 @@ __device__ __forceinline__ void store_tile_relu_dropout(const GemmArgs &g, const
       o.z = ((float)(rnd.v[2] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.z, 0.0f) : v.z) * inv : 0.0f;
       o.w = ((float)(rnd.v[3] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.w, 0.0f) : v.w) * inv : 0.0f;
       *reinterpret_cast<f4v *>(g.C + gm * g.ldc + gn) = o;
+      if (g.osign) {
+        // the 8 lanes of a row of this 32-column tile hold one sign word between
+        // them (rows are whole groups of 8 lanes, so the group is active together)
+        int w = ((o.x > 0.0f ? 1 : 0) | (o.y > 0.0f ? 2 : 0) | (o.z > 0.0f ? 4 : 0) | (o.w > 0.0f ? 8 : 0))
+                << (4 * (lane & 7));
+        w |= __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        w |= __builtin_amdgcn_mov_dpp(w, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        w |= __builtin_amdgcn_mov_dpp(w, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the 8
+        if ((lane & 7) == 0) g.osign[gm * g.ld_osign + (col0 >> 5)] = (uint32_t)w;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1001,7 +1015,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
                      const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
-                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream);
+                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream,
+                     uint32_t *out_signs = nullptr, int64_t ld_out_signs = 0);
 
 extern "C" int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                              const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
@@ -1063,6 +1078,16 @@ extern "C" int gcnx_gemm_relu_dropout_f32(int trans_a, int trans_b, int64_t M, i
                    1.0f, nullptr, nullptr, nullptr, 0, out_dropout, ws, ws_bytes, stream);
 }
 
+extern "C" int gcnx_gemm_relu_dropout_signs_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                                const float *A, int64_t lda, const float *B, int64_t ldb,
+                                                float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
+                                                const gcnx_dropout *out_dropout, uint32_t *sign_bits,
+                                                int64_t ld_words, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(out_dropout && sign_bits, GCNX_ERR_INVALID_ARG, "gemm_relu_dropout_signs: null argument");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, fuse_relu, nullptr, 0,
+                   1.0f, nullptr, nullptr, nullptr, 0, out_dropout, ws, ws_bytes, stream, sign_bits, ld_words);
+}
+
 extern "C" int gcnx_gemm_relu_dropout_supported(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
   (void)trans_b;
   return (!trans_a && nn_mfma_shape(M, N, K) && N % 4 == 0) ? 1 : 0;
@@ -1082,7 +1107,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                      int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
                      float beta, int fuse_relu, const float *gate, int64_t ldgate, float gate_scale,
                      const gcnx_dropout *a_drop, const int32_t *a_rows, const uint32_t *gate_bits,
-                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream) {
+                     int64_t ldbits, const gcnx_dropout *out_drop, void *ws, size_t ws_bytes, void *stream,
+                     uint32_t *out_signs, int64_t ld_out_signs) {
   GCNX_REQUIRE(M >= 0 && N >= 0 && K >= 0, GCNX_ERR_INVALID_ARG, "gemm: negative size");
   if (M == 0 || N == 0) return GCNX_OK;
   GCNX_REQUIRE(C && ldc >= N, GCNX_ERR_INVALID_ARG, "gemm: bad C");
@@ -1100,6 +1126,12 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   g.adrop_rows = nullptr; g.gate_bits = gate_bits; g.ldbits = ldbits;
   g.odrop_keep = 1.0f; g.odrop_seed = 0; g.odrop_offset = 0; g.odrop_ld = 0; g.odrop_col0 = 0; g.odrop_vec = 0;
   const bool want_odrop = out_drop && out_drop->keep < 1.0f;
+  g.osign = nullptr; g.ld_osign = 0;
+  if (out_signs) {
+    GCNX_REQUIRE(want_odrop && N % 32 == 0 && ld_out_signs * 32 >= N, GCNX_ERR_UNSUPPORTED,
+                 "gemm: sign words come with the fused output dropout (keep < 1), N %% 32 == 0, ld_words * 32 >= N");
+    g.osign = out_signs; g.ld_osign = ld_out_signs;
+  }
   if (want_odrop) {
     GCNX_REQUIRE(out_drop->keep > 0.0f && out_drop->ld >= N && out_drop->col0 >= 0, GCNX_ERR_INVALID_ARG,
                  "gemm: bad output dropout descriptor");

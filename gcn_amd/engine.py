@@ -138,11 +138,17 @@ class FullBatchGCN(object):
         self.hbits = None
         if not agg_first and sup_bits is not None and sup_bits(self.h) and (self.world == 1 or self.recompute):
             self.hbits = torch.empty((nl, self.h // 32), dtype=torch.int32, device=self.dev)
+        if agg_first and self.keep < 1.0 and self.h % 32 == 0 and not keep_masks:
+            # aggregate-first order: H' leaves the dense product, whose fused
+            # relu + dropout epilogue writes the sign words
+            sup_o = getattr(self.k, "gemm_supports_output_dropout", None)
+            if sup_o is not None and sup_o(False, nl, self.h, self.f):
+                self.hbits = torch.empty((nl, self.h // 32), dtype=torch.int32, device=self.dev)
         # with the sign words at hand the hidden-width backward product runs with a
         # factored operand: the rows of d(A P1) are formed inside the SpMM from the
         # class-width rows of dP2 and never stored
         sup_f = getattr(self.k, "spmm_supports_factored", None)
-        self.factored_bwd = bool(self.hbits is not None and self.keep > 0.0 and sup_f is not None and
+        self.factored_bwd = bool(not agg_first and self.hbits is not None and self.keep > 0.0 and sup_f is not None and
                                  sup_f(self.h, self.c))
 
     # --------------------------------------------------- halo rows by recompute
@@ -267,7 +273,10 @@ class FullBatchGCN(object):
         else:
             k.spmm(self.plan.csr, xin, out=self.ax, b2=xh)
         drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h, self.h, 0) if keep < 1.0 else None
-        k.gemm(self.ax, self.w1, out=self.hd, relu=True, dropout=drop)
+        if train and drop is not None and self.hbits is not None:
+            k.gemm(self.ax, self.w1, out=self.hd, relu=True, dropout=drop, sign_bits=self.hbits)
+        else:
+            k.gemm(self.ax, self.w1, out=self.hd, relu=True, dropout=drop)
         k.gemm(self.hd, self.w2, out=self.p2)
         self._aggregate("fwd", self.p2, self.z, relu=False)
         return xin, self.hd, None

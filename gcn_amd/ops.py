@@ -205,7 +205,7 @@ def spmm_add_autograd(a, b, c, alpha=1.0, relu=False):
 
 # ------------------------------------------------------------------------ GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu=False, gate=None,
-         gate_scale=1.0, a_dropout=None, a_dropout_rows=None, gate_bits=None, dropout=None):
+         gate_scale=1.0, a_dropout=None, a_dropout_rows=None, gate_bits=None, dropout=None, sign_bits=None):
     """``out = act(alpha * op(a) @ op(b) + beta * out)``, fp32.  Replaces
     ``dot(x, y, sparse=False)`` (reference gcn/layers.py:35).  With ``gate``
     (same shape as out) the epilogue is ``gate > 0 ? out * gate_scale : 0``: the
@@ -217,10 +217,14 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     gathered subset of the rows the mask is defined on).  ``gate_bits`` (uint32 /
     int32 [M, ceil(N/32)]) is the gate as one bit per element
     (:func:`pack_sign_bits`).  ``dropout=(keep, seed, offset, ld, col0)`` applies
-    dropout to the output behind the activation, as in :func:`spmm`."""
+    dropout to the output behind the activation, as in :func:`spmm`; with it,
+    ``sign_bits`` (int32 [M, N/32]) receives the sign pattern of the stored
+    output (fused epilogue only)."""
     lib = _lib.load()
     _check_dense(a, "a")
     _check_dense(b, "b")
+    if sign_bits is not None and (dropout is None or dropout[0] >= 1.0):
+        raise ValueError("sign_bits needs the fused output dropout (dropout with keep < 1)")
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
     if K != Kb:
@@ -245,7 +249,18 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
                 out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 and a.stride(0) % 4 == 0 and \
                 a.data_ptr() % 16 == 0 and (trans_b or N <= 32 or (b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0)) \
                 and int(offset) % 4 == 0 and int(ld) % 4 == 0 and int(col0) % 4 == 0
-            if fused:
+            if sign_bits is not None:
+                # sign words of the stored output straight from the fused epilogue
+                if not fused or N % 32 or sign_bits.dtype != torch.int32 or tuple(sign_bits.shape) != (M, N // 32) \
+                        or sign_bits.stride(1) != 1:
+                    raise ValueError("sign_bits: int32 [M, N / 32], fused output dropout only (see "
+                                     "gemm_supports_output_dropout), N % 32 == 0")
+                d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld), int(col0))
+                _lib.check(lib.gcnx_gemm_relu_dropout_signs_f32(
+                    int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out),
+                    out.stride(0), float(alpha), float(beta), 1 if relu else 0, C.byref(d), _ptr(sign_bits),
+                    sign_bits.stride(0), _ptr(ws), ws.numel(), _stream()))
+            elif fused:
                 d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld), int(col0))
                 _lib.check(lib.gcnx_gemm_relu_dropout_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a), a.stride(0),
                                                           _ptr(b), b.stride(0), _ptr(out), out.stride(0),

@@ -306,6 +306,19 @@ int gcnx_gemm_relu_dropout_f32(int trans_a, int trans_b, int64_t M, int64_t N, i
                                int fuse_relu, const gcnx_dropout *out_dropout,
                                void *ws, size_t ws_bytes, void *stream);
 
+/* gcnx_gemm_relu_dropout_f32 that also writes the sign pattern of the stored C
+ * (bit (n % 32) of sign_bits[m * ld_words + n / 32] set <=> element (m, n) > 0),
+ * the gate the backward pass needs (gcnx_gemm_bitgated_f32): the aggregate-first
+ * counterpart of gcnx_spmm_csr_signs_f32.  Needs keep < 1 and N % 32 == 0 on top
+ * of the conditions of gcnx_gemm_relu_dropout_f32.
+ * replaces: the relu and dropout gradients of gcn/layers.py:226,210 (their masks). */
+int gcnx_gemm_relu_dropout_signs_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+                                     const float *A, int64_t lda, const float *B, int64_t ldb,
+                                     float *C, int64_t ldc, float alpha, float beta,
+                                     int fuse_relu, const gcnx_dropout *out_dropout,
+                                     uint32_t *sign_bits, int64_t ld_words,
+                                     void *ws, size_t ws_bytes, void *stream);
+
 /* The gate as one bit per element: bit (n % 32) of gate_bits[m * ld_words +
  * n / 32] set <=> keep.  Used by the row-partitioned engine for the halo rows
  * of d(A P1): only the sign pattern of the remote rows of H' travels (32 bytes

@@ -120,6 +120,9 @@ class OracleKernels(object):
         g = self.gemm(d, w, trans_b=trans_w, gate_bits=gate_bits, gate_scale=gate_scale)
         return self.spmm(a, g, out=out)
 
+    def gemm_supports_output_dropout(self, trans_a, M, N, K):
+        return not trans_a and N % 4 == 0
+
     def gemm_supports_a_dropout(self, trans_a, M, N, K):
         return True
 
@@ -144,7 +147,7 @@ class OracleKernels(object):
         return self.dropout_dense(x, m, 1.0 / keep, out=out)
 
     def gemm(self, a, b, trans_a=False, trans_b=False, out=None, gate=None, gate_scale=1.0, a_dropout=None,
-             a_dropout_rows=None, gate_bits=None, relu=False, dropout=None, **kw):
+             a_dropout_rows=None, gate_bits=None, relu=False, dropout=None, sign_bits=None, **kw):
         an = a.contiguous().numpy()
         if a_dropout is not None and a_dropout[0] < 1.0:
             keep, seed, offset = a_dropout
@@ -171,6 +174,8 @@ class OracleKernels(object):
             cols = np.arange(r.shape[1], dtype=np.uint64)[None, :]
             m = self.o.bernoulli_mask_at(np.uint64(offset) + rows * np.uint64(ld) + np.uint64(col0) + cols, keep, seed)
             r = self.torch.where(self.torch.from_numpy(m != 0), r * np.float32(1.0 / keep), self.torch.zeros_like(r))
+        if sign_bits is not None:
+            self.pack_sign_bits(r, out=sign_bits)
         if out is None:
             return r
         out.copy_(r)

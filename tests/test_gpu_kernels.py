@@ -583,6 +583,13 @@ def test_gemm_output_dropout(env, ta, tb, M, N, K):
     cols = np.arange(N, dtype=np.uint64)[None, :]
     m = env["oracle"].bernoulli_mask_at(np.uint64(off) + rows * np.uint64(ld) + np.uint64(col0) + cols, 0.5, 4242)
     want = np.where(m != 0, plain * np.float32(2.0), np.float32(0))
+    if fused and N % 32 == 0:
+        # the same call can also hand out the sign words of what it stored
+        bits = torch.full((M, N // 32), -1, dtype=torch.int32, device=env["dev"])
+        again = env["ops"].gemm(at, bt, trans_a=bool(ta), trans_b=bool(tb), relu=True,
+                                dropout=(0.5, 4242, off, ld, col0), sign_bits=bits)
+        assert np.array_equal(again.cpu().numpy(), got)
+        assert torch.equal(bits, env["ops"].pack_sign_bits(again))
     if np.array_equal(got, want):
         return
     # shapes whose plain product is served by another kernel (another order of
