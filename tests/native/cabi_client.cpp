@@ -138,6 +138,64 @@ int main() {
     }
   std::printf("gemm: worst error %.3g of the summed magnitudes\n", worst);
   if (!(worst <= 1e-5)) return 1;
+  // ---- backward product with the factored operand ------------------------------
+  // C = A * G,  G[c, j] = bit(c, j) ? scale * sum_k D[c, k] * W2[j, k] : 0, G never stored
+  {
+    const int32_t fw = 256, inner = 16;
+    const int64_t words = fw / 32;
+    if (!gcnx_spmm_factored_supported(fw, inner)) return 1;
+    std::vector<float> hd((size_t)n_cols * inner), hw((size_t)fw * inner);
+    std::vector<uint32_t> hbits((size_t)n_cols * words);
+    for (auto &v : hd) v = (float)urand();
+    for (auto &v : hw) v = (float)urand() * 0.3f;
+    for (auto &v : hbits) v = rnd() & rnd();            // a quarter of the bits set
+    float *d_d = dev_alloc<float>(hd.size()), *d_w = dev_alloc<float>(hw.size());
+    float *d_fc = dev_alloc<float>((size_t)n_rows * fw);
+    uint32_t *d_bits = dev_alloc<uint32_t>(hbits.size());
+    if (!d_d || !d_w || !d_fc || !d_bits) return 2;
+    HIP_OK(hipMemcpy(d_d, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_bits, hbits.data(), hbits.size() * 4, hipMemcpyHostToDevice));
+    const size_t f_bytes = gcnx_spmm_workspace_bytes(nnz, fw);
+    void *f_ws = dev_alloc<char>(f_bytes);
+    GCNX_OK_(gcnx_spmm_csr_factored_f32(&a, d_chunk, d_d, inner, d_bits, words, nullptr, 0, nullptr, 0, n_cols,
+                                        d_w, inner, 1, inner, 2.0f, d_fc, fw, fw, f_ws, f_bytes, stream));
+    std::vector<float> fc((size_t)n_rows * fw);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(fc.data(), d_fc, fc.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<double> g((size_t)n_cols * fw), gm((size_t)n_cols * fw);
+    for (int64_t c0 = 0; c0 < n_cols; ++c0)
+      for (int j = 0; j < fw; ++j) {
+        double sum = 0.0, mg = 0.0;
+        if ((hbits[(size_t)c0 * words + j / 32] >> (j % 32)) & 1u)
+          for (int k = 0; k < inner; ++k) {
+            const double t = 2.0 * (double)hd[(size_t)c0 * inner + k] * (double)hw[(size_t)j * inner + k];
+            sum += t;
+            mg += std::fabs(t);
+          }
+        g[(size_t)c0 * fw + j] = sum;
+        gm[(size_t)c0 * fw + j] = mg;
+      }
+    std::vector<double> fref((size_t)n_rows * fw, 0.0), fmag((size_t)n_rows * fw, 0.0);
+    for (int64_t k = 0; k < nnz; ++k) {
+      const double v = (double)(float)val[k];
+      for (int j = 0; j < fw; ++j) {
+        fref[(size_t)row[k] * fw + j] += v * g[(size_t)col[k] * fw + j];
+        fmag[(size_t)row[k] * fw + j] += std::fabs(v) * gm[(size_t)col[k] * fw + j];
+      }
+    }
+    worst = 0.0;
+    for (size_t i = 0; i < fref.size(); ++i) {
+      const double err = std::fabs((double)fc[i] - fref[i]) / (fmag[i] > 1e-30 ? fmag[i] : 1e-30);
+      if (fmag[i] > 1e-30 && err > worst) worst = err;
+      if (fmag[i] <= 1e-30 && fc[i] != 0.0f) return 1;
+    }
+    std::printf("factored spmm: worst error %.3g of the summed magnitudes\n", worst);
+    if (!(worst <= 1e-5)) return 1;
+    // an inner size the kernel does not serve is a status, not a fault
+    if (gcnx_spmm_csr_factored_f32(&a, d_chunk, d_d, 8, d_bits, words, nullptr, 0, nullptr, 0, n_cols, d_w, 8, 1, 8,
+                                   2.0f, d_fc, fw, fw, f_ws, f_bytes, stream) != GCNX_ERR_UNSUPPORTED) return 1;
+  }
   std::printf("C ABI client OK (abi %d)\n", gcnx_abi_version());
   return 0;
 }
