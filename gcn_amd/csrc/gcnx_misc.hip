@@ -101,6 +101,43 @@ __global__ __launch_bounds__(kBlock) void xent_rows_kernel(
 // lane j of a group holds class j, so logits / labels / grad are read and written
 // fully coalesced and the row maxima, sums and first-maximum indices are formed
 // with wavefront shuffles inside the group.
+// Partner value for step `off` of a butterfly reduction inside a group of lanes.
+// Up to 16 lanes the exchange is a DPP move on the vector ALU (no LDS crossbar):
+// quad permutes for 1 and 2; for 4 and 8 the mirror of 8 / 16 lanes, which pairs
+// the same sub-groups as xor does once every lane of a sub-group holds the
+// sub-group's result (true after the earlier steps of the reduction).
+template <int OFF>
+__device__ __forceinline__ int butterfly_i(int v) {
+  if constexpr (OFF == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+  else if constexpr (OFF == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+  else if constexpr (OFF == 4) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);
+  else if constexpr (OFF == 8) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);
+  else return __shfl_xor(v, OFF, kWave);
+}
+template <int OFF>
+__device__ __forceinline__ float butterfly_f(float v) {
+  return __int_as_float(butterfly_i<OFF>(__float_as_int(v)));
+}
+// One reduction step for the four running values of a row.
+template <int OFF, int G>
+__device__ __forceinline__ void xent_step_max(float &zmax, float &ymax) {
+  if constexpr (OFF < G) {
+    zmax = fmaxf(zmax, butterfly_f<OFF>(zmax));
+    ymax = fmaxf(ymax, butterfly_f<OFF>(ymax));
+    xent_step_max<OFF * 2, G>(zmax, ymax);
+  }
+}
+template <int OFF, int G>
+__device__ __forceinline__ void xent_step_sum(int &az, int &ay, float &se, float &ysum) {
+  if constexpr (OFF < G) {
+    az = min(az, butterfly_i<OFF>(az));
+    ay = min(ay, butterfly_i<OFF>(ay));
+    se += butterfly_f<OFF>(se);
+    ysum += butterfly_f<OFF>(ysum);
+    xent_step_sum<OFF * 2, G>(az, ay, se, ysum);
+  }
+}
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
     int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
@@ -121,21 +158,11 @@ __global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
     const float z = (valid && in) ? logits[row * ld + sub] : ninf;
     const float y = (valid && in) ? labels[row * ldl + sub] : ninf;
     float zmax = z, ymax = y;
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) {
-      zmax = fmaxf(zmax, __shfl_xor(zmax, off, kWave));
-      ymax = fmaxf(ymax, __shfl_xor(ymax, off, kWave));
-    }
+    xent_step_max<1, G>(zmax, ymax);
     int az = (in && z == zmax) ? sub : G, ay = (in && y == ymax) ? sub : G;  // first maximum wins
     const float e = (valid && in) ? __expf(z - zmax) : 0.0f;
     float se = e, ysum = (valid && in) ? y : 0.0f;
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) {
-      az = min(az, __shfl_xor(az, off, kWave));
-      ay = min(ay, __shfl_xor(ay, off, kWave));
-      se += __shfl_xor(se, off, kWave);
-      ysum += __shfl_xor(ysum, off, kWave);
-    }
+    xent_step_sum<1, G>(az, ay, se, ysum);
     if (valid) {
       const bool on = mask[row] != 0;
       if (on && in) loss += (double)(-y * ((z - zmax) - __logf(se)));
