@@ -176,6 +176,78 @@ __global__ __launch_bounds__(kBlock) void xent_rows_group_kernel(
   if (threadIdx.x == 0) hit_part[blockIdx.x] = hit;
 }
 
+// The same with four consecutive classes per lane (16-byte loads and stores:
+// a wavefront instruction moves 1 KiB instead of 256 bytes): L = pow2 >= nc / 4
+// lanes per row, nc a multiple of 4, rows 16-byte aligned.
+template <int L>
+__global__ __launch_bounds__(kBlock) void xent_rows_vec4_kernel(
+    int64_t n, int32_t nc, const float *__restrict__ logits, int64_t ld,
+    const float *__restrict__ labels, int64_t ldl, const uint8_t *__restrict__ mask,
+    const double *__restrict__ msum_p, double msum_known, float *__restrict__ grad, int64_t ldg,
+    double *__restrict__ loss_part, double *__restrict__ hit_part) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  __shared__ double sh[kWavesPerBlock];
+  constexpr int RPB = kBlock / L;
+  const double msum = msum_known > 0.0 ? msum_known : *msum_p;
+  const float wgt = msum > 0.0 ? (float)(1.0 / msum) : 0.0f;
+  const int sub = threadIdx.x % L;
+  const int c0 = 4 * sub;
+  const bool in = c0 < nc;
+  const float ninf = -__builtin_inff();
+  double loss = 0.0, hit = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n; base += (int64_t)gridDim.x * RPB) {
+    const int64_t row = base + threadIdx.x / L;
+    const bool valid = row < n;
+    f4 z = f4(ninf), y = f4(ninf);
+    if (valid && in) {
+      z = *reinterpret_cast<const f4 *>(logits + row * ld + c0);
+      y = *reinterpret_cast<const f4 *>(labels + row * ldl + c0);
+    }
+    float zmax = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+    float ymax = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+    xent_step_max<1, L>(zmax, ymax);
+    int az = 4 * L, ay = 4 * L;                       // first maximum wins
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      if (in && z[j] == zmax) az = c0 + j;
+      if (in && y[j] == ymax) ay = c0 + j;
+    }
+    f4 e = f4(0.0f);
+    float se = 0.0f, ysum = 0.0f;
+    if (valid && in) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        e[j] = __expf(z[j] - zmax);
+        se += e[j];
+        ysum += y[j];
+      }
+    }
+    xent_step_sum<1, L>(az, ay, se, ysum);
+    if (valid) {
+      const bool on = mask[row] != 0;
+      if (on && in) {
+        const float lse = __logf(se);
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += -y[j] * ((z[j] - zmax) - lse);
+        loss += (double)t;
+      }
+      if (on && sub == 0 && az == ay) hit += 1.0;
+      if (grad && in) {
+        const float w = on ? wgt : 0.0f, inv = ysum / se;
+        f4 gq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gq[j] = (e[j] * inv - y[j]) * w;
+        *reinterpret_cast<f4 *>(grad + row * ldg + c0) = gq;
+      }
+    }
+  }
+  loss = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+  hit = block_sum(hit, sh);
+  if (threadIdx.x == 0) hit_part[blockIdx.x] = hit;
+}
+
 __global__ __launch_bounds__(kBlock) void xent_final_kernel(int nb, const double *__restrict__ ws_msum,
                                                            double msum_known,
                                                            const double *__restrict__ loss_part,
@@ -520,7 +592,18 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
 #define GCNX_XENT(G)                                                                          \
   hipLaunchKernelGGL((xent_rows_group_kernel<G>), dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, \
                      ld, labels, ldl, mask, msum, known, grad, ldg, lp, hp)
-  if (n_class > 64) {
+  const bool vec4 = n_class % 4 == 0 && n_class <= 64 && ld % 4 == 0 && ldl % 4 == 0 && aligned16(logits) &&
+                    aligned16(labels) && (!grad || (ldg % 4 == 0 && aligned16(grad)));
+#define GCNX_XENT4(L)                                                                          \
+  hipLaunchKernelGGL((xent_rows_vec4_kernel<L>), dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, \
+                     ld, labels, ldl, mask, msum, known, grad, ldg, lp, hp)
+  if (vec4) {
+    if (n_class > 32) GCNX_XENT4(16);
+    else if (n_class > 16) GCNX_XENT4(8);
+    else if (n_class > 8) GCNX_XENT4(4);
+    else if (n_class > 4) GCNX_XENT4(2);
+    else GCNX_XENT4(1);
+  } else if (n_class > 64) {
     hipLaunchKernelGGL(xent_rows_kernel, dim3(nb), dim3(kBlock), 0, st, n, n_class, logits, ld, labels,
                        ldl, mask, msum, known, grad, ldg, lp, hp);
   } else if (n_class > 32) GCNX_XENT(64);
@@ -531,6 +614,7 @@ extern "C" int gcnx_masked_softmax_xent_f32(int64_t n, int32_t n_class, const fl
   else if (n_class > 1) GCNX_XENT(2);
   else GCNX_XENT(1);
 #undef GCNX_XENT
+#undef GCNX_XENT4
   hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(kBlock), 0, st, nb, msum, known, lp, hp, out_loss_acc);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;

@@ -249,7 +249,9 @@ def test_gemm_mfma_layout_asymmetric(env):
 
 
 # ----------------------------------------------------------------- glue kernels
-@pytest.mark.parametrize("n,c", [(1, 2), (2708, 7), (3327, 6), (100000, 16), (70000, 3)])
+@pytest.mark.parametrize("n,c", [(1, 2), (2708, 7), (3327, 6), (100000, 16), (70000, 3),
+                                 # class counts that are multiples of 4: four classes per lane
+                                 (5000, 4), (5001, 8), (4097, 12), (3000, 32), (2000, 48), (999, 64), (300, 100)])
 def test_masked_softmax_xent(env, n, c):
     torch = env["torch"]
     rng = np.random.RandomState(n + c)
