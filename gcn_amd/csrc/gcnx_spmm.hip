@@ -845,6 +845,33 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const SpmmArgs a) {
   }
 }
 
+// The same for narrow operands (at most 32 lanes of 4 columns): a wavefront
+// takes 64 / LW chunk boundaries, LW lanes each, instead of idling most lanes.
+template <int LW>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_narrow_kernel(const SpmmArgs a) {
+  typedef typename vec_of<4>::type V;
+  constexpr int S = kWave / LW;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = (int)(threadIdx.x >> 6);
+  const int64_t c = ((int64_t)blockIdx.x * kWavesPerBlock + wid) * S + lane / LW;
+  if (c + 1 >= a.n_chunks) return;
+  const int col0 = (lane % LW) * 4;
+  if (col0 >= a.width) return;
+  const int64_t r = a.chunk_row[(c + 1) * a.chunk_mul];
+  const int64_t start = a.row_ptr[r];
+  if (start >= (c + 1) * (int64_t)a.chunk || start < c * (int64_t)a.chunk) return;
+  const int64_t end = a.row_ptr[r + 1];
+  const int64_t cl = (end - 1) / a.chunk;
+  const float *p = a.partial + col0;
+  V sum = vload<4>(p + ((size_t)c * 2 + 1) * a.pwidth);
+  for (int64_t cc = c + 1; cc <= cl; ++cc) sum += vload<4>(p + (size_t)cc * 2 * a.pwidth);
+  const V out = epilogue_store<4>(a, r, col0, sum);
+  if constexpr (LW >= 8) {
+    // a boundary's lanes form whole groups of 8 (widths with sign words are multiples of 32)
+    if (a.sign_bits) store_sign_word(a, r, col0, lane, out);
+  }
+}
+
 // nnz == 0: every row is empty, C = act(beta * C).
 __global__ void spmm_empty_kernel(const SpmmArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1127,7 +1154,16 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   GCNX_CHECK_LAUNCH();
   if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
   if (k.n_chunks > 1) {
-    if (v4) hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
+    if (v4 && lanes <= 32) {
+      // narrow operand: several boundaries per wavefront
+#define GCNX_FIXN(L) hipLaunchKernelGGL((spmm_fixup_narrow_kernel<L>), \
+    dim3((unsigned)ceil_div(k.n_chunks, (int64_t)kWavesPerBlock * (kWave / L))), dim3(kBlock), 0, st, k)
+      if (lanes > 16) GCNX_FIXN(32);
+      else if (lanes > 8) GCNX_FIXN(16);
+      else if (lanes > 4) GCNX_FIXN(8);
+      else GCNX_FIXN(4);
+#undef GCNX_FIXN
+    } else if (v4) hipLaunchKernelGGL((spmm_fixup_kernel<4>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     else hipLaunchKernelGGL((spmm_fixup_kernel<1>), dim3(gx, gy), dim3(kBlock), 0, st, k);
     GCNX_CHECK_LAUNCH();
   }
