@@ -304,18 +304,27 @@ def main():
             ms = [s.elapsed_time(e) for s, e in ev_used]
             avg = sum(ms) / len(ms) * 1e-3
             bytes_ = algorithmic_bytes(a.nnz, a.n_rows, args.hidden)
-            traffic = None
+            # HBM traffic of this kernel comes from rocprofv3 --pmc passes (FETCH_SIZE,
+            # WRITE_SIZE; separate runs of tools/spmm_bench.py on the same matrix and
+            # width), folded into bytes in profiles/spmm_hbm_traffic.json.  It is NOT
+            # measured in this run: the counters need the profiler attached.
+            traffic, traffic_source = None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")) as fh:
                     rec = json.load(fh)
-                if rec.get("scale") == scale and rec.get("width") == args.hidden and world == 1:
+                if rec.get("scale") == scale and rec.get("width") == args.hidden and world == 1 and \
+                        rec.get("edge_factor", 8) == args.edge_factor:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = "static: profiles/spmm_hbm_traffic.json <- " + str(rec.get("source"))
             except (OSError, ValueError):
                 pass
             result["roofline"] = {
-                "bound": "hbm", "kernel": "spmm_chunk_kernel<4,8> (A_hat x [N,%d] fp32)" % args.hidden,
+                "bound": "hbm",
+                "kernel": "spmm_chunk_kernel<4,8> + its fix-up pass spmm_fixup_kernel<4> (A_hat x [N,%d] fp32)"
+                          % args.hidden,
                 "achieved": bytes_ / avg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic,
+                "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
+                "timed_window": "HIP events on the launch stream around the main pass and the fix-up pass",
                 "algorithmic_bytes_per_launch": bytes_, "avg_launch_ms": avg * 1e3,
                 "launches_timed": len(ms), "kernel_nnzF_per_s": a.nnz * args.hidden / avg,
                 "compulsory_bytes_per_launch": 8 * a.nnz + 8 * a.n_rows * args.hidden + 8 * (a.n_rows + 1),

@@ -344,6 +344,28 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(int64_t n, float *__restri
   }
 }
 
+// out[0] = (add ? add[0] : 0) + scale * sum_i w[i]^2 / 2.  One workgroup: the
+// weight matrices this is for hold 10^4..10^5 elements, and a single fixed
+// reduction tree keeps the sum reproducible.
+constexpr int kL2Block = 1024;
+__global__ __launch_bounds__(kL2Block) void l2_loss_kernel(int64_t n, const float *__restrict__ w, float scale,
+                                                           const float *__restrict__ add,
+                                                           float *__restrict__ out) {
+  __shared__ float part[kL2Block / kWave];
+  float s = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += kL2Block) s = fmaf(w[i], w[i], s);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kL2Block / kWave; ++k) t += part[k];
+    out[0] = (add ? add[0] : 0.0f) + scale * (0.5f * t);
+  }
+}
+
 // One wavefront per 64 output words: word (i, w) collects the signs of
 // x[row(i)][32w .. 32w+31] (bit j set <=> element > 0) with a wavefront ballot
 // per 64 columns, so reads are coalesced and every lane writes at most once.
@@ -665,6 +687,14 @@ extern "C" int gcnx_adam_step_dev_f32(int64_t n, float *w, const float *grad, fl
   if (n == 0) return GCNX_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, as_stream(stream), n, w,
                      grad, m, v, lr, beta1, beta2, eps, weight_decay, t_dev);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_l2_loss_f32(int64_t n, const float *w, float scale, const float *add, float *out,
+                                void *stream) {
+  GCNX_REQUIRE(n >= 0 && out && (n == 0 || w), GCNX_ERR_INVALID_ARG, "l2_loss: bad argument");
+  hipLaunchKernelGGL(l2_loss_kernel, dim3(1), dim3(kL2Block), 0, as_stream(stream), n, w, scale, add, out);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

@@ -78,6 +78,7 @@ def _transform(run, x, w, keep, key, relu):
 
 
 _MERGED = {}
+tf.on_reset(_MERGED.clear)
 
 
 def _merged_support(supports):
@@ -121,6 +122,7 @@ def _merged_support(supports):
 
 
 _IDENTITY_CHECKED = {}
+tf.on_reset(_IDENTITY_CHECKED.clear)
 
 
 def _is_identity(csr):

@@ -11,6 +11,7 @@ def _loss_and_acc(preds, labels, mask):
 
 
 _PAIRS = {}
+tf.on_reset(_PAIRS.clear)
 
 
 def _pair(preds, labels, mask):

@@ -73,7 +73,7 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
                 not spmm_supports_sign_bits(width):
             raise ValueError("sign_bits: int32 [n_rows, width / 32] on A's device, width % 32 == 0, no mask")
         with torch.cuda.device(a.device):
-            need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+            need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
             ws = WORKSPACE.get(need, a.device)
             _lib.check(lib.gcnx_spmm_csr_signs_f32(
                 a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
@@ -82,7 +82,7 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
                 _ptr(sb), sb.stride(0), _ptr(ws), ws.numel(), _stream()))
         return out
     with torch.cuda.device(a.device):
-        need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+        need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
         ws = WORKSPACE.get(need, a.device)
         _lib.check(lib.gcnx_spmm_csr_split_f32(
             a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
@@ -133,7 +133,7 @@ def spmm_factored(a, d, w, gate_bits, gate_scale=1.0, trans_w=False, out=None, d
     elif tuple(out.shape) != (a.n_rows, width) or out.stride(1) != 1:
         raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), (a.n_rows, width)))
     with torch.cuda.device(d.device):
-        need = lib.gcnx_spmm_workspace_bytes(a.nnz, width)
+        need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
         ws = WORKSPACE.get(need, d.device)
         _lib.check(lib.gcnx_spmm_csr_factored_f32(
             a.struct_ref(), _ptr(a.chunk_row), _ptr(d), d.stride(0), _ptr(gate_bits), gate_bits.stride(0),
@@ -625,6 +625,25 @@ def adam_step(w, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
                                               float(lr), float(beta1), float(beta2), float(eps),
                                               float(weight_decay), int(t), _stream()))
     return w
+
+
+def l2_loss(w, scale=1.0, add=None):
+    """One-element tensor ``(add or 0) + scale * sum(w ** 2) / 2`` (reference
+    gcn/models.py:148-149: ``weight_decay * tf.nn.l2_loss(var)`` added into the
+    loss).  No gradient is recorded: the decay gradient ``scale * w`` is applied
+    inside :func:`adam_step` (``weight_decay``)."""
+    lib = _lib.load()
+    w = w.detach()
+    if w.device.type != "cuda" or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("w must be a contiguous float32 CUDA tensor")
+    if add is not None:
+        add = add.detach()
+        if add.device != w.device or add.dtype != torch.float32 or add.numel() != 1:
+            raise ValueError("add must be a one-element float32 tensor on w's device")
+    out = torch.empty(1, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.gcnx_l2_loss_f32(w.numel(), _ptr(w), float(scale), _ptr(add), _ptr(out), _stream()))
+    return out
 
 
 def profile_spmm_events(start, stop):

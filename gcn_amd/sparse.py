@@ -62,7 +62,13 @@ class Csr(object):
     ``val`` fp32 [nnz]; rows ordered by column, duplicates in input order.
     ``input_index[slot]`` is the position of the entry in the tuple the matrix
     was built from (dropout masks are drawn in that order,
-    reference gcn/layers.py:21-27)."""
+    reference gcn/layers.py:21-27).  ``spmm_chunk`` is the per-matrix dispatch
+    hint of the SpMM entry points (0: the library chooses; 64..512: chunk
+    kernels with that many nonzeros per wavefront); new matrices take the class
+    attribute ``default_spmm_chunk``, which the kernel tests override to run
+    every case through each code path."""
+
+    default_spmm_chunk = 0
 
     def __init__(self, n_rows, n_cols, row_ptr, col_idx, val, input_index=None):
         self.n_rows = int(n_rows)
@@ -75,7 +81,8 @@ class Csr(object):
         self.device = row_ptr.device
         self._t = None
         self._struct = _lib.CsrStruct(self.n_rows, self.n_cols, self.nnz,
-                                      row_ptr.data_ptr(), col_idx.data_ptr(), val.data_ptr())
+                                      row_ptr.data_ptr(), col_idx.data_ptr(), val.data_ptr(),
+                                      int(self.default_spmm_chunk))
         lib = _lib.load()
         n_chunks = lib.gcnx_spmm_num_chunks(self.nnz)
         self.chunk_row = torch.empty(n_chunks + 1, dtype=torch.int32, device=self.device)
@@ -88,6 +95,14 @@ class Csr(object):
 
     def struct_ref(self):
         return C.byref(self._struct)
+
+    @property
+    def spmm_chunk(self):
+        return int(self._struct.spmm_chunk)
+
+    @spmm_chunk.setter
+    def spmm_chunk(self, value):
+        self._struct.spmm_chunk = int(value)
 
     # ---------------------------------------------------------------- builders
     @classmethod

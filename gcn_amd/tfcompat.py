@@ -14,6 +14,7 @@ gcn/utils.py:143-144).
 Only what the reference uses is provided; anything else raises AttributeError.
 """
 import argparse
+import collections
 import contextlib
 import os
 import sys
@@ -130,9 +131,10 @@ class Node(object):
 
     # scalar arithmetic used when the loss is assembled (gcn/models.py:146-153)
     def __add__(self, other):
-        return Node(lambda run, a, b: a + b, (self, other))
+        return _Sum([self, other])
 
-    __radd__ = __add__
+    def __radd__(self, other):
+        return _Sum([other, self])
 
     def __mul__(self, other):
         return Node(lambda run, a, b: a * b, (self, other))
@@ -144,6 +146,87 @@ class Node(object):
 
     def __eq__(self, other):
         return self is other
+
+
+class _Sum(Node):
+    """Sum of loss terms.  Nested sums are flattened and literal zeros dropped, so
+    ``0 + wd * l2_loss(w) + cross_entropy`` (reference gcn/models.py:146-153) is
+    one node whose terms the optimizer can inspect: weight-decay terms
+    (:class:`L2Term`) are then evaluated by ``gcnx_l2_loss_f32`` chained onto the
+    other terms, and their gradient is applied inside the Adam kernel."""
+
+    def __init__(self, terms):
+        flat = []
+        for t in terms:
+            if isinstance(t, _Sum):
+                flat.extend(t.terms)
+            elif isinstance(t, (int, float)) and not isinstance(t, bool) and t == 0:
+                continue
+            else:
+                flat.append(t)
+        self.terms = flat
+        self.l2_terms = [t for t in flat if isinstance(t, L2Term)]
+        plain = [t for t in flat if not isinstance(t, L2Term)]
+        super(_Sum, self).__init__(self._eval, plain, "sum")
+
+    def without(self, dropped):
+        """The sum of the remaining terms (None when nothing remains)."""
+        rest = [t for t in self.terms if not any(t is d for d in dropped)]
+        if not rest:
+            return None
+        return rest[0] if len(rest) == 1 else _Sum(rest)
+
+    def _eval(self, run, *vals):
+        acc = None
+        for v in vals:
+            acc = v if acc is None else acc + v
+        for t in self.l2_terms:
+            if run.folds(t):
+                # value only (no tape): chained onto the running sum by the kernel
+                # when that is a device scalar, so no scalar add kernels are needed
+                w = run.value(t.var)
+                if isinstance(acc, torch.Tensor) and acc.is_cuda and acc.dtype == torch.float32 and acc.numel() == 1:
+                    acc = ops.l2_loss(w, t.coef, add=acc.reshape(1)).reshape(())
+                else:
+                    v = ops.l2_loss(w, t.coef).reshape(())
+                    acc = v if acc is None else acc + v
+            else:
+                v = run.value(t)
+                acc = v if acc is None else acc + v
+        return acc if acc is not None else 0.0
+
+
+class L2Term(Node):
+    """``coef * tf.nn.l2_loss(var)`` = coef * sum(var ** 2) / 2."""
+
+    def __init__(self, var, coef=1.0):
+        super(L2Term, self).__init__(self._eval, (var,), "l2_loss")
+        self.var = var
+        self.coef = float(coef)
+
+    def _eval(self, run, w):
+        # stand-alone use (not folded into an optimizer step): differentiable
+        return _L2Fn.apply(w, self.coef)
+
+    def __mul__(self, other):
+        if isinstance(other, (int, float)) and not isinstance(other, bool):
+            return L2Term(self.var, self.coef * float(other))
+        return Node.__mul__(self, other)
+
+    __rmul__ = __mul__
+
+
+class _L2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, coef):
+        ctx.save_for_backward(w)
+        ctx.coef = coef
+        return ops.l2_loss(w.contiguous(), coef).reshape(())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        return w * (dy * ctx.coef), None
 
 
 class _Shape(object):
@@ -302,9 +385,21 @@ def global_variables_initializer():
     return Node(init, (), "init")
 
 
+_RESET_HOOKS = []
+
+
+def on_reset(fn):
+    """Register a callable run by :func:`reset_default_graph` (modules that keep
+    per-graph caches of device objects clear them there)."""
+    _RESET_HOOKS.append(fn)
+    return fn
+
+
 def reset_default_graph():
     del _GLOBAL_VARIABLES[:]
     del _SCOPE[:]
+    for fn in _RESET_HOOKS:
+        fn()
 
 
 # ------------------------------------------------------------------------ ops
@@ -361,7 +456,7 @@ class _NN(object):
 
     @staticmethod
     def l2_loss(var):
-        return Node(lambda run, v: (v * v).sum() * 0.5, (var,))
+        return L2Term(var)
 
     @staticmethod
     def softmax_cross_entropy_with_logits(logits=None, labels=None):
@@ -395,10 +490,23 @@ summary = _Summary()
 
 # ------------------------------------------------------------------ optimizer
 class _OptOp(Node):
+    """``optimizer.minimize(loss)``.  Weight-decay terms of the loss
+    (``coef * l2_loss(variable)`` added at the top level) are split off: their
+    gradient ``coef * w`` is added inside the Adam kernel (``decay``), and only
+    ``rest`` -- the remaining terms -- goes through the autograd tape."""
+
     def __init__(self, optimizer, loss):
         super(_OptOp, self).__init__(None, (), "opt_op")
         self.optimizer = optimizer
         self.loss = loss
+        self.folded = []
+        self.rest = loss
+        if isinstance(loss, _Sum):
+            self.folded = [t for t in loss.l2_terms if isinstance(t.var, Variable)]
+            self.rest = loss.without(self.folded)
+        self.decay = {}
+        for t in self.folded:
+            self.decay[t.var] = self.decay.get(t.var, 0.0) + t.coef
 
 
 class AdamOptimizer(object):
@@ -415,8 +523,9 @@ class AdamOptimizer(object):
     def minimize(self, loss):
         return _OptOp(self, loss)
 
-    def apply(self, variables, grads):
-        """One update of every variable.  The step count lives in device memory
+    def apply(self, variables, grads, decay=None):
+        """One update of every variable; ``decay`` maps a variable to the
+        coefficient of its weight-decay term (gradient added in the kernel).  The step count lives in device memory
         and is advanced by a kernel, so that the launches can be recorded in a
         HIP graph and replayed."""
         if self._step_dev is None:
@@ -424,12 +533,16 @@ class AdamOptimizer(object):
         if not torch.cuda.is_current_stream_capturing():
             self.step += 1
         ops.counter_add(self._step_dev, 1)
+        decay = decay or {}
         for v, g in zip(variables, grads):
+            wd = decay.get(v, 0.0)
             if g is None:
-                continue
+                if not wd:
+                    continue
+                g = torch.zeros_like(v.tensor)     # a variable reached by its decay term only
             with torch.no_grad():
                 ops.adam_step(v.tensor, g.contiguous(), v.adam_m, v.adam_v, self.learning_rate,
-                              self._step_dev, self.beta1, self.beta2, self.epsilon)
+                              self._step_dev, self.beta1, self.beta2, self.epsilon, weight_decay=wd)
 
 
 class _Saver(object):
@@ -461,10 +574,17 @@ train = _Train()
 class _Run(object):
     """State of one ``sess.run``: feed values, memo, dropout masks."""
 
-    def __init__(self, sess, feed):
+    def __init__(self, sess, feed, folded=()):
         self.sess = sess
         self.feed = feed
         self.memo = {}
+        self._folded = set(id(t) for t in folded)
+
+    def folds(self, l2_term):
+        """Whether this run takes the value of a weight-decay term without a
+        tape: an optimizer step of this run applies its gradient inside Adam, or
+        nothing is differentiated at all."""
+        return id(l2_term) in self._folded or not torch.is_grad_enabled()
 
     def dropout_mask(self, key, n, keep):
         provider = self.sess.mask_provider
@@ -483,7 +603,7 @@ class _Run(object):
             hit = self.sess._cache.get(key)
             if hit is None or hit[0] is not node:
                 hit = (node, torch.from_numpy(np.ascontiguousarray(node, dtype=np.float32)).to(device()))
-                self.sess._cache[key] = hit
+                self.sess._remember(key, hit)
             return hit[1]
         if not isinstance(node, Node):
             return node
@@ -517,8 +637,13 @@ class Session(object):
     loop does: gcn/train_normal.py:89-93); the values of fed arrays are read at
     upload time only, exactly as without graphs."""
 
+    # fed objects whose device copies are kept (least recently used dropped first);
+    # a training loop feeds a handful of objects over and over, a caller that
+    # feeds fresh arrays every step must not grow device memory without bound
+    CACHE_ENTRIES = 64
+
     def __init__(self, config=None):
-        self._cache = {}
+        self._cache = collections.OrderedDict()
         self.run_counter = 0
         self._run_dev = None   # device copy of run_counter: the dropout kernels read it
         # hook: mask_provider(key, n, keep) -> uint8 array or None; lets a
@@ -538,6 +663,7 @@ class Session(object):
         key = id(value)
         hit = self._cache.get(key)
         if hit is not None and hit[0] is value:
+            self._cache.move_to_end(key)
             return hit[1]
         if ph.sparse:
             out = SparseValue(Csr.from_tuple(value, device()), source=value)
@@ -550,26 +676,35 @@ class Session(object):
                 out.mask_total = float(np.count_nonzero(arr))   # read by the masked loss
             else:
                 out = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device())
-        self._cache[key] = (value, out)
+        self._remember(key, (value, out))
         return out
+
+    def _remember(self, key, entry):
+        self._cache[key] = entry
+        self._cache.move_to_end(key)
+        while len(self._cache) > self.CACHE_ENTRIES:
+            self._cache.popitem(last=False)
 
     def _execute(self, flist, feed):
         """Issue every launch of one run on the current stream (no host
         synchronisation once the fed values are resident); returns the fetched
         values as device tensors / Python objects."""
         ops.counter_add(self._run_dev, 1)
-        run = _Run(self, feed)
         opt_ops = [f for f in flist if isinstance(f, _OptOp)]
+        run = _Run(self, feed, [t for op in opt_ops for t in op.folded])
         results = [None] * len(flist)
         with torch.set_grad_enabled(bool(opt_ops)):
             for i, f in enumerate(flist):
                 if not isinstance(f, _OptOp):
                     results[i] = run.value(f)
             for op in opt_ops:
-                loss = run.value(op.loss)
                 variables = [v for v in _GLOBAL_VARIABLES if v.tensor is not None]
-                grads = torch.autograd.grad(loss, [v.tensor for v in variables], allow_unused=True)
-                op.optimizer.apply(variables, grads)
+                loss = run.value(op.rest) if op.rest is not None else None
+                if isinstance(loss, torch.Tensor) and loss.requires_grad:
+                    grads = torch.autograd.grad(loss, [v.tensor for v in variables], allow_unused=True)
+                else:
+                    grads = [None] * len(variables)
+                op.optimizer.apply(variables, grads, op.decay)
         return [r.detach() if isinstance(r, torch.Tensor) else r for r in results]
 
     @staticmethod
@@ -626,6 +761,9 @@ class Session(object):
                 else:
                     ent["graph"] = graph
                     ent["workspace"] = WORKSPACE.buffers()
+                    # the recording reads the device copies of the fed objects: keep them
+                    # alive with the graph even if the session cache drops them later
+                    ent["device_refs"] = [self._cache[id(v)] for v in feed.values() if id(v) in self._cache]
         if ent is not None and "graph" in ent:
             ent["graph"].replay()
             self.graph_replays += 1
@@ -646,6 +784,7 @@ class Session(object):
 
     def close(self):
         self._cache.clear()
+        self._graphs.clear()    # recorded HIP graphs and the memory pools they hold
 
     def __enter__(self):
         return self

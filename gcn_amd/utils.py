@@ -128,6 +128,33 @@ def load_graph(dataset_str, data_dir=None):
     return adjacency_from_dict_of_lists(_find_dataset(dataset_str, data_dir)["graph"])
 
 
+def load_pubmed_synthetic_features(data_dir=None, nnz_per_row=50, n_features=500, seed=123):
+    """Pubmed with its REAL graph, labels and splits and shape-matched SYNTHETIC
+    features: ``ind.pubmed.allx`` is not distributed with the reference tree, so
+    the bag-of-words matrix [19717, 500] is replaced by ``nnz_per_row`` ones per
+    row at seeded random columns (duplicates add up).  Same return tuple as
+    :func:`load_data`.  Timing and kernel parity only: accuracy on these features
+    means nothing."""
+    p = _find_dataset("pubmed", data_dir)
+    reorder = np.asarray(p["test_index"])
+    sorted_idx = np.sort(reorder)
+    labels = np.vstack((p["ally"], p["ty"])).astype(np.float64)
+    labels[reorder, :] = labels[sorted_idx, :]
+    n = labels.shape[0]
+    rng = np.random.RandomState(seed)
+    rows = np.repeat(np.arange(n), nnz_per_row)
+    cols = rng.randint(0, n_features, size=n * nnz_per_row)
+    feats = sp.csr_matrix((np.ones(n * nnz_per_row, dtype=np.float32), (rows, cols)), shape=(n, n_features))
+    feats.data[:] = 1.0
+    n_train = len(p["y"])
+    train_mask = sample_mask(range(n_train), n)
+    val_mask = sample_mask(range(n_train, n_train + 500), n)
+    test_mask = sample_mask(sorted_idx.tolist(), n)
+    keep = lambda m: np.where(m[:, None], labels, 0.0)
+    return (adjacency_from_dict_of_lists(p["graph"]), feats.tolil(), keep(train_mask), keep(val_mask),
+            keep(test_mask), train_mask, val_mask, test_mask)
+
+
 def _one_tuple(mx):
     if not sp.isspmatrix_coo(mx):
         mx = mx.tocoo()

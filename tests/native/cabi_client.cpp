@@ -82,7 +82,7 @@ int main() {
   gcnx_csr a = {n_rows, n_cols, nnz, d_rp, d_ci, d_v};
   int32_t *d_chunk = dev_alloc<int32_t>((size_t)gcnx_spmm_num_chunks(nnz) + 1);
   GCNX_OK_(gcnx_spmm_chunk_table(&a, d_chunk, stream));
-  size_t sp_bytes = gcnx_spmm_workspace_bytes(nnz, width);
+  size_t sp_bytes = gcnx_spmm_workspace_bytes(&a, width);
   void *sp_ws = dev_alloc<char>(sp_bytes);
   GCNX_OK_(gcnx_spmm_csr_f32(&a, d_chunk, d_b, width, d_c, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 1,
                              sp_ws, sp_bytes, stream));
@@ -156,7 +156,7 @@ int main() {
     HIP_OK(hipMemcpy(d_d, hd.data(), hd.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_bits, hbits.data(), hbits.size() * 4, hipMemcpyHostToDevice));
-    const size_t f_bytes = gcnx_spmm_workspace_bytes(nnz, fw);
+    const size_t f_bytes = gcnx_spmm_workspace_bytes(&a, fw);
     void *f_ws = dev_alloc<char>(f_bytes);
     GCNX_OK_(gcnx_spmm_csr_factored_f32(&a, d_chunk, d_d, inner, d_bits, words, nullptr, 0, nullptr, 0, n_cols,
                                         d_w, inner, 1, inner, 2.0f, d_fc, fw, fw, f_ws, f_bytes, stream));

@@ -354,11 +354,22 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().gcnx_abi_version() == 1
+    assert _lib.load().gcnx_abi_version() == _lib.ABI_VERSION == 2
     assert _lib.load().gcnx_spmm_chunk_nnz() == 64
     # pure host-side queries work without a GPU
     assert _lib.load().gcnx_spmm_num_chunks(1025) == 17
-    assert _lib.load().gcnx_spmm_workspace_bytes(1025, 7) == 17 * 2 * 8 * 4
+    m = _lib.CsrStruct(10, 10, 1025, None, None, None)
+    assert _lib.load().gcnx_spmm_workspace_bytes(ctypes.byref(m), 7) == 17 * 2 * 8 * 4
+    # the dispatch hint travels with the matrix descriptor (no process-wide knobs)
+    m.spmm_chunk = 512
+    assert _lib.load().gcnx_spmm_workspace_bytes(ctypes.byref(m), 7) == 3 * 2 * 8 * 4
+    m.spmm_chunk = 100        # rounded up to 128
+    assert _lib.load().gcnx_spmm_workspace_bytes(ctypes.byref(m), 7) == 9 * 2 * 8 * 4
+    assert not any("row_path_limit" in n or "min_chunk" in n for n in declared)
+    # the header's scratch-array size and the Python mirror agree
+    text = open(os.path.join(ROOT, "include", "gcnx.h")).read()
+    assert re.search(r"#define\s+GCNX_SPMM_STATIC_SCRATCH_BYTES\s+\(32u << 20\)", text)
+    assert _lib.SPMM_STATIC_SCRATCH_BYTES == 32 << 20
 
 
 def test_product_never_imports_the_oracle():
@@ -379,3 +390,71 @@ def test_ops_fail_loudly_without_gpu():
         sparse.Csr.from_coo([0], [0], [1.0], (1, 1), "cpu")
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+# ------------------------------------------------------------- initialisers
+def test_initialisers_range_dtype_and_seed_determinism():
+    """glorot / uniform / zeros / ones (reference gcn/inits.py:5-27): bounds
+    +-sqrt(6 / (fan_in + fan_out)) resp. +-scale, fp32, the given shape; the
+    same graph seed reproduces the same bits, another layer (another random op
+    of the same graph) draws other numbers, another seed too.  TensorFlow's own
+    random stream cannot be reproduced, so the values themselves are not pinned
+    (parity runs inject weights)."""
+    from gcn_amd import inits, tfcompat as tf
+
+    def draw(seed):
+        tf.reset_default_graph()
+        tf.set_random_seed(seed)
+        with tf.variable_scope("m"):
+            g1 = inits.glorot([1433, 16], name="weights_0")
+            g2 = inits.glorot([1433, 16], name="weights_1")
+            u = inits.uniform([40, 3], scale=0.05, name="u")
+            z = inits.zeros([16], name="bias")
+            o = inits.ones([5, 2], name="o")
+        return g1, g2, u, z, o
+
+    g1, g2, u, z, o = draw(123)
+    r = np.sqrt(6.0 / (1433 + 16))
+    for v, shape in ((g1, (1433, 16)), (g2, (1433, 16)), (u, (40, 3)), (z, (16,)), (o, (5, 2))):
+        assert v._init_value.dtype == np.float32 and v._init_value.shape == shape == tuple(v.static_shape)
+    for g in (g1, g2):
+        a = g._init_value
+        assert a.min() >= -r and a.max() <= r
+        assert a.min() < -0.9 * r and a.max() > 0.9 * r          # the range is used, not a fraction of it
+        assert abs(a.mean()) < 0.02 * r and abs(a.std() - r / np.sqrt(3.0)) < 0.02 * r   # uniform, not normal
+    assert np.abs(u._init_value).max() <= 0.05 and np.abs(u._init_value).max() > 0.04
+    assert not z._init_value.any() and (o._init_value == 1.0).all()
+    assert g1.name == "m/weights_0:0" and z.name == "m/bias:0"
+    # another layer of the same graph: another draw
+    assert not np.array_equal(g1._init_value, g2._init_value)
+    # same seed => same bits; other seed => other numbers
+    h1, h2, hu, _, _ = draw(123)
+    for a, b in ((g1, h1), (g2, h2), (u, hu)):
+        assert np.array_equal(a._init_value.view(np.uint32), b._init_value.view(np.uint32))
+    k1 = draw(124)[0]
+    assert not np.array_equal(g1._init_value, k1._init_value)
+    tf.reset_default_graph()
+
+
+def test_loss_expression_splits_weight_decay_terms():
+    """0 + wd * l2_loss(w) + cross-entropy (reference gcn/models.py:146-153) is
+    one flat sum; minimize() hands the decay terms to the Adam kernel and keeps
+    the rest for the tape."""
+    from gcn_amd import tfcompat as tf
+    tf.reset_default_graph()
+    w = tf.Variable(tf.zeros([3, 2]), name="w")
+    b = tf.Variable(tf.zeros([2]), name="b")
+    ce = tf.Node(lambda run: None, (), "ce")
+    loss = 0
+    loss += 5e-4 * tf.nn.l2_loss(w)
+    loss += tf.nn.l2_loss(b) * 2.0
+    loss += ce
+    assert isinstance(loss, tf._Sum) and len(loss.terms) == 3 and len(loss.l2_terms) == 2
+    op = tf.train.AdamOptimizer(0.01).minimize(loss)
+    assert op.rest is ce
+    assert op.decay == {w: 5e-4, b: 2.0}
+    only_decay = tf.train.AdamOptimizer(0.01).minimize(0 + 0.5 * tf.nn.l2_loss(w))
+    assert only_decay.rest is None and only_decay.decay == {w: 0.5}
+    plain = tf.train.AdamOptimizer(0.01).minimize(ce)
+    assert plain.rest is ce and plain.decay == {}
+    tf.reset_default_graph()

@@ -30,16 +30,13 @@ def spmm_path(request):
     boundaries, the fix-up pass does most stores) and with 512-nonzero chunks
     (the configuration the large graphs run: several 64-wide batches per
     wavefront)."""
-    from gcn_amd import _lib
-    lib = _lib.load()
-    row_before = lib.gcnx_spmm_row_path_limit(-1)
-    chunk_before = lib.gcnx_spmm_min_chunk(-1)
+    from gcn_amd.sparse import Csr
+    before = Csr.default_spmm_chunk
     if request.param != "default":
-        lib.gcnx_spmm_row_path_limit(0)
-        lib.gcnx_spmm_min_chunk(64 if request.param == "chunk64" else 512)
+        # the dispatch hint is a field of the matrix descriptor (gcnx_csr::spmm_chunk)
+        Csr.default_spmm_chunk = 64 if request.param == "chunk64" else 512
     yield request.param
-    lib.gcnx_spmm_row_path_limit(row_before)
-    lib.gcnx_spmm_min_chunk(chunk_before)
+    Csr.default_spmm_chunk = before
 
 
 def _csr_np(csr):
@@ -400,9 +397,42 @@ def test_spmm_output_dropout_epilogue(env, width, ld, col0):
         return
     # shapes whose plain product is served by another kernel (another order of
     # the k terms): the kept / dropped pattern is exact, the values agree to rounding
+    _assert_dropout_fallback(env, got, want, m, rp, ci, v, b)
+
+
+def _assert_dropout_fallback(env, got, want, m, rp, ci, v, b):
+    """The check behind exact equality in test_spmm_output_dropout_epilogue: the
+    kept / dropped pattern is exact and kept values agree to fp32 rounding,
+    measured against the size of the summed terms, 2 * |A| |B| (the yardstick of
+    helpers.assert_close_to_f64, from the oracle's fp64 product of the absolute
+    values)."""
     assert np.array_equal(got[m == 0], want[m == 0])
-    mag = 2.0 * env["oracle"].gemm_f64(np.abs(a), np.abs(b), bool(ta), bool(tb))
-    assert float((np.abs(got.astype(np.float64) - want) / np.maximum(mag, 1e-30)).max()) <= RTOL
+    _, mag = env["oracle"].spmm_csr_f64(rp, ci, np.abs(v), np.abs(b))
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert float((err / np.maximum(2.0 * mag, 1e-30)).max()) <= RTOL
+
+
+def test_dropout_epilogue_fallback_check_is_live(env):
+    """The tolerance branch above has to work when it is needed: a result that
+    differs from the reference value by one rounding passes it, a wrong kept /
+    dropped pattern or a wrong value fails it."""
+    rng = np.random.RandomState(4)
+    rows, cols, vals = random_coo(rng, 50, 40, 600)
+    rp, ci, v, _ = env["oracle"].csr_from_coo(rows, cols, vals.astype(np.float32), (50, 40))
+    b = rng.standard_normal((40, 8)).astype(np.float32)
+    plain = np.maximum(env["oracle"].spmm_csr(rp, ci, v, b), 0)
+    m = (rng.random_sample(plain.shape) < 0.5).astype(np.uint8)
+    want = np.where(m != 0, plain * np.float32(2.0), np.float32(0))
+    nudged = np.where(m != 0, np.nextafter(want, np.float32(np.inf), dtype=np.float32), want)
+    _assert_dropout_fallback(env, nudged, want, m, rp, ci, v, b)
+    wrong = want.copy()
+    wrong[m != 0] *= np.float32(1.001)
+    with pytest.raises(AssertionError):
+        _assert_dropout_fallback(env, wrong, want, m, rp, ci, v, b)
+    leaked = want.copy()
+    leaked[m == 0] = 1.0
+    with pytest.raises(AssertionError):
+        _assert_dropout_fallback(env, leaked, want, m, rp, ci, v, b)
 
 
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 1, 3000, 256, 16), (0, 0, 700, 33, 20), (1, 0, 256, 16, 30000),
@@ -800,3 +830,22 @@ def test_spmm_factored_rejects_unsupported(env):
     torch, ops, dev = env["torch"], env["ops"], env["dev"]
     assert not ops.spmm_supports_factored(256, 8)
     assert not ops.spmm_supports_factored(48, 16)
+
+
+@pytest.mark.parametrize("n", [1, 63, 1024, 1433 * 16, 256 * 256 + 3])
+def test_l2_loss_kernel(env, n):
+    """scale * sum(w^2) / 2 chained onto a device scalar (reference
+    gcn/models.py:148-149), against the fp64 sum; reproducible."""
+    torch = env["torch"]
+    rng = np.random.RandomState(n)
+    w = rng.standard_normal(n).astype(np.float32)
+    wt = torch.from_numpy(w).to(env["dev"])
+    want = 5e-4 * 0.5 * float((w.astype(np.float64) ** 2).sum())
+    got = env["ops"].l2_loss(wt, 5e-4)
+    assert got.shape == (1,) and abs(float(got.item()) - want) <= 1e-5 * want + 1e-12
+    base = torch.tensor([1.25], dtype=torch.float32, device=env["dev"])
+    got2 = env["ops"].l2_loss(wt, 5e-4, add=base)
+    assert abs(float(got2.item()) - (1.25 + want)) <= 1e-5 * (1.25 + want)
+    assert float(base.item()) == 1.25
+    again = env["ops"].l2_loss(wt, 5e-4)
+    assert np.array_equal(again.cpu().numpy().view(np.uint32), got.cpu().numpy().view(np.uint32))

@@ -15,30 +15,13 @@ import sys
 import time
 
 import numpy as np
-import scipy.sparse as sp
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def pubmed_with_synthetic_features():
     from gcn_amd import utils
-    p = utils._find_dataset("pubmed", None)
-    reorder = np.asarray(p["test_index"])
-    sorted_idx = np.sort(reorder)
-    labels = np.vstack((p["ally"], p["ty"])).astype(np.float64)
-    labels[reorder, :] = labels[sorted_idx, :]
-    n = labels.shape[0]
-    rng = np.random.RandomState(123)
-    rows = np.repeat(np.arange(n), 50)
-    cols = rng.randint(0, 500, size=n * 50)
-    feats = sp.csr_matrix((np.ones(n * 50, dtype=np.float32), (rows, cols)), shape=(n, 500))
-    feats.data[:] = 1.0
-    n_train = len(p["y"])
-    tm = utils.sample_mask(range(n_train), n)
-    vm = utils.sample_mask(range(n_train, n_train + 500), n)
-    sm = utils.sample_mask(sorted_idx.tolist(), n)
-    keep = lambda m: np.where(m[:, None], labels, 0.0)
-    return (utils.adjacency_from_dict_of_lists(p["graph"]), feats.tolil(), keep(tm), keep(vm), keep(sm), tm, vm, sm)
+    return utils.load_pubmed_synthetic_features()
 
 
 def main():
