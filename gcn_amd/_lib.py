@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCNX_LIB overrides the path (kernel-variant experiments during development)
 LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
+ABI_VERSION = 2
+
 OK = 0
 ERR_INVALID_ARG = -1
 ERR_WORKSPACE = -2
@@ -34,7 +36,8 @@ class DropoutStruct(C.Structure):
 class CsrStruct(C.Structure):
     """Mirror of ``struct gcnx_csr``."""
     _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64),
-                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("val", C.c_void_p)]
+                ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("val", C.c_void_p),
+                ("spmm_chunk", C.c_int32)]
 
 
 _i32, _i64, _u64, _f32, _f64 = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -46,15 +49,13 @@ SIGNATURES = {
     "gcnx_abi_version": (_int, []),
     "gcnx_last_error": (C.c_char_p, []),
     "gcnx_spmm_chunk_nnz": (_int, []),
-    "gcnx_spmm_row_path_limit": (_i64, [_i64]),
-    "gcnx_spmm_min_chunk": (_int, [_int]),
     "gcnx_csr_from_coo_workspace_bytes": (_sz, [_i64, _i64]),
     "gcnx_csr_from_coo": (_int, [_i64, _i64, _i64, _p, _p, _i64, _p, _int, _p, _p, _p, _p, _p, _sz, _p]),
     "gcnx_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gcnx_csr_transpose": (_int, [_csr_p, _p, _p, _p, _p, _p, _sz, _p]),
     "gcnx_spmm_num_chunks": (_i64, [_i64]),
     "gcnx_spmm_chunk_table": (_int, [_csr_p, _p, _p]),
-    "gcnx_spmm_workspace_bytes": (_sz, [_i64, _i32]),
+    "gcnx_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),
     "gcnx_spmm_csr_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32,
                                  _int, _p, _sz, _p]),
     "gcnx_spmm_csr_split_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32,
@@ -101,6 +102,7 @@ SIGNATURES = {
     "gcnx_relu_dropout_bwd_philox_f32": (_int, [_i64, _p, _p, _f32, _u64, _u64, _p, _p]),
     "gcnx_relu_dropout_bwd_f32": (_int, [_i64, _p, _p, _p, _f32, _p, _p]),
     "gcnx_adam_step_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
+    "gcnx_l2_loss_f32": (_int, [_i64, _p, _f32, _p, _p, _p]),
     "gcnx_adam_step_dev_f32": (_int, [_i64, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p]),
     "gcnx_normalize_csr_f64": (_int, [_csr_p, _i64, _p, _p, _i64, _p, _p, _p]),
     "gcnx_rmat_workspace_bytes": (_sz, []),
@@ -129,8 +131,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.gcnx_abi_version() != 1:
-        raise ImportError("libgcnhip.so ABI version %d, expected 1" % lib.gcnx_abi_version())
+    if lib.gcnx_abi_version() != ABI_VERSION:
+        raise ImportError("libgcnhip.so ABI version %d, expected %d" % (lib.gcnx_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GCNX_ABI_VERSION 1
+#define GCNX_ABI_VERSION 2
 
 typedef enum gcnx_status {
   GCNX_OK = 0,
@@ -46,7 +46,14 @@ typedef enum gcnx_status {
 } gcnx_status;
 
 /* CSR matrix resident on the device.  Entries of a row are ordered by column,
- * duplicates kept in input order. */
+ * duplicates kept in input order.
+ * spmm_chunk is a per-matrix dispatch hint read by the SpMM entry points and by
+ * gcnx_spmm_workspace_bytes: 0 (the default of a zero-initialised struct) lets
+ * the library choose (one wavefront per row for small short-rowed matrices,
+ * otherwise chunks of 64..512 nonzeros per wavefront by matrix size); 64, 128,
+ * 256 or 512 sends every product with this matrix down the chunk kernels with
+ * that many nonzeros per wavefront (other values are rounded up to the next of
+ * these).  The library keeps no dispatch state of its own. */
 typedef struct gcnx_csr {
   int64_t n_rows;
   int64_t n_cols;
@@ -54,6 +61,7 @@ typedef struct gcnx_csr {
   const int64_t *row_ptr; /* [n_rows + 1] */
   const int32_t *col_idx; /* [nnz] */
   const float *val;       /* [nnz] */
+  int32_t spmm_chunk;     /* dispatch hint, see above; 0 = chosen by the library */
 } gcnx_csr;
 
 /* Dropout fused into the epilogue of a product (replaces tf.nn.dropout on the
@@ -121,20 +129,15 @@ int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream);
  * Sums are formed in fp32 in slot order inside a chunk; rows that span several
  * chunks are completed from per-chunk partial sums in chunk order, so results
  * are bitwise reproducible run to run.
- * Matrices of at most gcnx_spmm_row_path_limit(-1) nonzeros whose dense operand
- * fits 32 lanes (128 columns with 16-byte aligned rows, else 32) are summed one
- * wavefront per row instead (slot-strided terms, then a shuffle tree): also a
- * fixed function of the input.
+ * Matrices of at most 2^18 nonzeros (and at most 64 per row on average) whose
+ * dense operand fits 32 lanes (128 columns with 16-byte aligned rows, else 32)
+ * are summed one wavefront per row instead (slot-strided terms, then a shuffle
+ * tree), unless a->spmm_chunk asks for the chunk kernels: also a fixed function
+ * of the input.
+ * Workspace: sized for the matrix (only a->nnz and a->spmm_chunk are read) and
+ * the operand width; pass the same spmm_chunk to the query and to the call.
  */
-size_t gcnx_spmm_workspace_bytes(int64_t nnz, int32_t width);
-/* Tuning knob (process-wide): nonzero count up to which the wavefront-per-row
- * kernel is used; returns the previous value; a negative argument only reads.
- * 0 sends every matrix down the chunk kernels. */
-int64_t gcnx_spmm_row_path_limit(int64_t max_nnz);
-/* Tuning knob (process-wide): smallest number of nonzeros per wavefront in the
- * chunk kernels (rounded up to 64, 128, 256 or 512; default 64, 512 restores
- * one fixed chunk size); returns the previous value; negative only reads. */
-int gcnx_spmm_min_chunk(int min_chunk);
+size_t gcnx_spmm_workspace_bytes(const gcnx_csr *a, int32_t width);
 int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       const float *B, int64_t ldb, float *C, int64_t ldc,
                       int32_t width, float alpha, float beta,
@@ -225,11 +228,12 @@ int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                          int64_t lds, int32_t width, float *dst, int64_t ldd,
                          void *stream);
 
-/* Measurement hook (no counterpart in the reference): while set, every
- * gcnx_spmm_csr_f32 call made by this thread records hipEvent `start` right
- * before and `stop` right after its main kernel, on the launch stream, so a
- * benchmark can time that kernel alone inside a longer timed region.  Pass
- * NULL, NULL to clear. */
+/* Measurement hook (no counterpart in the reference): while set, every SpMM
+ * call made by this thread records hipEvent `start` right before its first
+ * kernel and `stop` right after its last one (the main pass and, when rows are
+ * cut by chunk boundaries, the fix-up pass), on the launch stream, so a
+ * benchmark can time the product alone inside a longer timed region.  The
+ * setting is thread-local.  Pass NULL, NULL to clear. */
 void gcnx_profile_spmm_events(void *start, void *stop);
 
 /* ---- Multi-support sum  C = act(sum_i A_i * P_i)  as ONE product -----------
@@ -432,6 +436,15 @@ int gcnx_relu_dropout_bwd_f32(int64_t n, const float *y, const float *dy,
 int gcnx_adam_step_f32(int64_t n, float *w, const float *grad, float *m,
                        float *v, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int64_t t, void *stream);
+
+/* replaces: tf.nn.l2_loss(var) and its addition into the loss,
+ * gcn/models.py:148-149.  out[0] = (add ? add[0] : 0) + scale * sum(w^2) / 2;
+ * add (nullable, one device float) lets the caller chain the weight-decay terms
+ * onto the cross-entropy without separate scalar kernels; add == out is
+ * allowed.  One fixed reduction tree: reproducible.  The gradient of this term
+ * is not produced here: gcnx_adam_step_f32 folds it in (weight_decay). */
+int gcnx_l2_loss_f32(int64_t n, const float *w, float scale, const float *add,
+                     float *out, void *stream);
 
 /* Same update with the step count t (>= 1) read from device memory when the
  * kernel runs (the bias correction is formed on the device), for launches
