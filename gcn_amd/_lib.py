@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
 ABI_VERSION = 2
+SPMM_STATIC_SCRATCH_BYTES = 32 << 20   # GCNX_SPMM_STATIC_SCRATCH_BYTES of include/gcnx.h
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -58,6 +59,7 @@ SIGNATURES = {
     "gcnx_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),
     "gcnx_spmm_csr_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32,
                                  _int, _p, _sz, _p]),
+    "gcnx_spmm_csr_static_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i32, _f32, _f32, _p, _p, _f32, _int, _p]),
     "gcnx_spmm_csr_split_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32,
                                        _p, _p, _f32, _int, _p, _p, _sz, _p]),
     "gcnx_spmm_signs_supported": (_int, [_i32]),

@@ -17,6 +17,8 @@
 // (slot 0: the row began in an earlier chunk; slot 1: it begins here and runs
 // on); spmm_fixup_kernel adds them in chunk order and applies the epilogue, so
 // the result does not depend on scheduling.
+#include <mutex>
+
 #include "gcnx_common.h"
 #include "gcnx_philox.h"
 
@@ -1165,6 +1167,54 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   // the timed window covers the whole product: main pass and fix-up pass
   if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
   return GCNX_OK;
+}
+
+// ---- the product for callers that cannot allocate --------------------------
+// The partial sums of rows cut by chunk boundaries go to a file-scope device
+// array instead of a caller workspace.  Every GPU the library runs on holds its
+// own copy of the array at its own address until the process ends; the address
+// is looked up once per device (hipGetSymbolAddress with that device current)
+// and only that pointer is ever handed to kernels -- the array's name in host
+// code is a host-side stand-in, not a device address.
+static __device__ __align__(256) unsigned char scratch[GCNX_SPMM_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[kMaxDevices] = {};   // per device, written once under the mutex
+
+// Device address of `scratch` on the current device (looked up on first use).
+int static_scratch(void **out) {
+  int dev = -1;
+  GCNX_CHECK_HIP(hipGetDevice(&dev));
+  GCNX_REQUIRE(dev >= 0 && dev < kMaxDevices, GCNX_ERR_UNSUPPORTED, "spmm_static: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void *p = nullptr;
+    GCNX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    GCNX_REQUIRE(p != nullptr, GCNX_ERR_HIP, "spmm_static: the scratch array has no address on device %d", dev);
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return GCNX_OK;
+}
+}  // namespace
+
+extern "C" int gcnx_spmm_csr_static_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
+                                        int64_t ldb, float *C, int64_t ldc, int32_t width, float alpha,
+                                        float beta, const uint8_t *val_mask, const int64_t *mask_index,
+                                        float mask_scale, int fuse_relu, void *stream) {
+  GCNX_REQUIRE(a, GCNX_ERR_INVALID_ARG, "spmm_static: null matrix");
+  const size_t need = gcnx_spmm_workspace_bytes(a, width);
+  GCNX_REQUIRE(need <= (size_t)GCNX_SPMM_STATIC_SCRATCH_BYTES, GCNX_ERR_WORKSPACE,
+               "spmm_static: this product needs %zu bytes of partial sums, the built-in scratch array holds %zu; "
+               "use gcnx_spmm_csr_f32 with a caller workspace",
+               need, (size_t)GCNX_SPMM_STATIC_SCRATCH_BYTES);
+  void *ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != GCNX_OK) return rc;
+  return spmm_impl(a, chunk_row, B, ldb, nullptr, 0, a->n_cols, C, ldc, width, alpha, beta, val_mask, mask_index,
+                   mask_scale, fuse_relu, nullptr, nullptr, 0, ws, (size_t)GCNX_SPMM_STATIC_SCRATCH_BYTES, stream);
 }
 
 #ifndef GCNX_FACTORED_U

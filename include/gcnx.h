@@ -145,6 +145,27 @@ int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
                       float mask_scale, int fuse_relu, void *ws,
                       size_t ws_bytes, void *stream);
 
+/* gcnx_spmm_csr_f32 for callers that cannot allocate or carry a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  The partial sums of rows cut by
+ * chunk boundaries go to a device array built into the library
+ * (GCNX_SPMM_STATIC_SCRATCH_BYTES; every GPU the library runs on holds one until
+ * the process ends) instead of (ws, ws_bytes); the call makes no hipMalloc,
+ * hipFree or other allocating call.  Products whose
+ * gcnx_spmm_workspace_bytes(a, width) exceeds the array are rejected with
+ * GCNX_ERR_WORKSPACE (at the default dispatch: up to about 8.4 M nonzeros at
+ * width 256, 134 M at width 16).  Nothing in the array has to start at zero
+ * (every slot the fix-up pass reads is written by the main pass of the same
+ * call), so the contents a previous call left behind are harmless; but all calls
+ * on one GPU share the one array: calls that overlap on the same GPU (two
+ * streams, two threads) race.  Same results, bit for bit, as gcnx_spmm_csr_f32. */
+#define GCNX_SPMM_STATIC_SCRATCH_BYTES (32u << 20)
+int gcnx_spmm_csr_static_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                             const float *B, int64_t ldb, float *C, int64_t ldc,
+                             int32_t width, float alpha, float beta,
+                             const uint8_t *val_mask, const int64_t *mask_index,
+                             float mask_scale, int fuse_relu, void *stream);
+
 /* The same product with the dense operand in two pieces: rows [0, split_col) of
  * the operand are read from B, rows [split_col, n_cols) from B2 (row 0 of B2 is
  * operand row split_col).  Used by the row-partitioned engine: B holds the

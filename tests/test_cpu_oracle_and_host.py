@@ -366,6 +366,10 @@ def test_cabi_exports_every_declared_symbol():
     m.spmm_chunk = 100        # rounded up to 128
     assert _lib.load().gcnx_spmm_workspace_bytes(ctypes.byref(m), 7) == 9 * 2 * 8 * 4
     assert not any("row_path_limit" in n or "min_chunk" in n for n in declared)
+    # the header's scratch-array size and the Python mirror agree
+    text = open(os.path.join(ROOT, "include", "gcnx.h")).read()
+    assert re.search(r"#define\s+GCNX_SPMM_STATIC_SCRATCH_BYTES\s+\(32u << 20\)", text)
+    assert _lib.SPMM_STATIC_SCRATCH_BYTES == 32 << 20
 
 
 def test_product_never_imports_the_oracle():
