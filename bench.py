@@ -6,6 +6,7 @@ RMAT graph (the headline configuration: RMAT 2^24 nodes, avg degree 16, F=256, h
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+    ... --gpus 8 --edge-factor 16      # RMAT 2^27 nodes, average degree 32 over 8 GPUs
 
 A step is one optimisation step = one epoch of the full-batch model: forward
 (dropout, X W1, A_hat P1 + relu, dropout, H W2, A_hat P2), masked loss,
@@ -108,6 +109,9 @@ def main():
                     help="first layer as A_hat (X' W1) like the reference (default) or as (A_hat X') W1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
                     "ranks sharing one GPU)")
+    ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
+                    help="several GPUs over RCCL: per-step halo exchange / all-reduce through the C ABI "
+                         "(gcnx_halo_allgather_f32, default) or through torch.distributed")
     args = ap.parse_args()
 
     t_start = time.time()
@@ -200,9 +204,17 @@ def main():
                 return t
         engine_cls = HostStagedGather
 
+    comm = None
+    if world > 1 and args.backend == "nccl" and args.exchange == "cabi":
+        # the per-step exchanges and all-reduces run inside libgcnhip.so (grouped
+        # ncclSend / ncclRecv on its own communicator); torch.distributed only
+        # carries the communicator id and the set-up lists
+        from gcn_amd.comm import RcclComm
+        comm = RcclComm(group, world, rank, dev)
+        note("C-ABI communicator up")
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
-                                row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
-                                slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order)
+                       row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
+                       slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -291,6 +303,8 @@ def main():
                 "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
                 "halo_rows_rank0": (model.plan.n_halo if model.plan is not None else 0),
                 "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
+                "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
+                             if comm is not None else "torch.distributed " + args.backend),
                 "order": args.order,
                 "spmm_per_step": ("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
                                   if args.order == "reference" else
@@ -351,6 +365,8 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier(group=group)
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -20,6 +20,8 @@ ERR_WORKSPACE = -2
 ERR_INDEX_RANGE = -3
 ERR_HIP = -4
 ERR_UNSUPPORTED = -5
+ERR_COMM = -6
+COMM_ID_BYTES = 128
 
 
 class GcnxError(RuntimeError):
@@ -32,6 +34,12 @@ class DropoutStruct(C.Structure):
     """Mirror of ``struct gcnx_dropout``."""
     _fields_ = [("keep", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("ld", C.c_int64), ("col0", C.c_int64)]
+
+
+class HaloExchangeStruct(C.Structure):
+    """Mirror of ``struct gcnx_halo_exchange``."""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("h_send_rows", C.POINTER(C.c_int64)),
+                ("h_recv_rows", C.POINTER(C.c_int64)), ("send_idx", C.c_void_p)]
 
 
 class CsrStruct(C.Structure):
@@ -86,6 +94,12 @@ SIGNATURES = {
     "gcnx_halo_plan_workspace_bytes": (_sz, [_i64]),
     "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
     "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "gcnx_comm_available": (_int, []),
+    "gcnx_comm_unique_id": (_int, [_p]),
+    "gcnx_comm_create": (_int, [_i32, _i32, _p, C.POINTER(C.c_void_p)]),
+    "gcnx_comm_destroy": (_int, [_p]),
+    "gcnx_halo_allgather_f32": (_int, [C.POINTER(HaloExchangeStruct), _p, _p, _i64, _i64, _i32, _p, _p, _p]),
+    "gcnx_comm_allreduce_sum_f32": (_int, [_p, _p, _i64, _p]),
     "gcnx_profile_spmm_events": (None, [_p, _p]),
     "gcnx_coo_interleave_supports": (_int, [_i32, _p, _p, _p, _i64, _p, _int, _p, _p, _p, _p]),
     "gcnx_gemm_workspace_bytes": (_sz, [_int, _int, _i64, _i64, _i64]),

@@ -14,9 +14,10 @@ and the backward products  A_hat^T dZ,  H'^T dP2,  dP2 W2^T,  A_hat^T dH,
 X'^T dP1.  With P ranks, rank p owns a contiguous block of rows of A_hat and of
 every activation; before each SpMM the rows of the dense operand that the block
 references on other ranks (the halo, gcn_amd/halo.py) are fetched with a
-variable-size all-to-all (RCCL over xGMI via torch.distributed), issued in column
-slabs on the communication stream so that the SpMM of slab s overlaps the
-transfer of slab s+1.  For the two hidden-width products the halo rows are not
+variable-size all-to-all -- grouped RCCL sends and receives over xGMI issued by
+libgcnhip.so (gcn_amd/comm.py, gcnx_halo_allgather_f32) -- in column slabs on the
+communication stream, so that the SpMM of slab s overlaps the transfer of slab
+s+1.  For the two hidden-width products the halo rows are not
 sent at all but recomputed by the GPU that needs them (``halo_mode``): the
 features are constant, so each GPU keeps a copy of the remote feature rows it
 references and forms dropout(X) W1 for them itself; in the backward pass only
@@ -46,7 +47,7 @@ class FullBatchGCN(object):
     def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
-                 kernels=None, keep_masks=False, halo_mode="auto", order="reference"):
+                 kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -55,8 +56,14 @@ class FullBatchGCN(object):
         rows over all ranks.  ``halo_mode``: "exchange" sends the halo rows of
         every dense operand; "recompute" forms the hidden-width halo rows
         locally (see the module text); "auto" picks "recompute" when the
-        kernels serve it for these shapes."""
+        kernels serve it for these shapes.  ``comm`` (a gcn_amd.comm.RcclComm):
+        the per-step exchanges and all-reduces go through the C ABI
+        (gcnx_halo_allgather_f32 / gcnx_comm_allreduce_sum_f32, RCCL bound inside
+        libgcnhip.so) on the communicator's own stream; without it they go
+        through torch.distributed on ``group`` (the gloo rehearsal).  The
+        set-up exchanges of the halo plan always use ``group``."""
         self.k = kernels if kernels is not None else _hip_ops
+        self.comm = comm
         self.a = a_local
         self.at = a_bwd_local if a_bwd_local is not None else a_local
         self.x = x_local
@@ -191,9 +198,9 @@ class FullBatchGCN(object):
             nc = min(slab, w - c0)
             sb = self.sendbuf[0][:plan.n_send * nc].view(plan.n_send, nc)
             hb = self.halobuf[0][:plan.n_halo * nc].view(plan.n_halo, nc)
-            if plan.n_send:
-                self.k.gather_rows(src[:, c0:c0 + nc], plan.send_idx, sb)
-            self._all_to_all(hb, sb, plan.recv_counts, plan.send_counts)
+            work = self._exchange_start(plan, src, c0, nc, sb, hb)
+            if work is not None:
+                work.wait()
             if plan.n_halo:
                 dst[:plan.n_halo, c0:c0 + nc].copy_(hb)
 
@@ -219,9 +226,7 @@ class FullBatchGCN(object):
             nc = min(slab, w - c0)
             sb = self.sendbuf[i % 2][:plan.n_send * nc].view(plan.n_send, nc)
             hb = self.halobuf[i % 2][:plan.n_halo * nc].view(plan.n_halo, nc)
-            if plan.n_send:
-                self.k.gather_rows(src[:, c0:c0 + nc], plan.send_idx, sb)
-            works[i] = (self._all_to_all_start(hb, sb, plan.recv_counts, plan.send_counts), hb, c0, nc)
+            works[i] = (self._exchange_start(plan, src, c0, nc, sb, hb), hb, c0, nc)
 
         launch(0)
         for i in range(len(starts)):
@@ -234,9 +239,22 @@ class FullBatchGCN(object):
                         b2=hb if plan.n_halo else None,
                         dropout=None if dropout is None else dropout + (dst.shape[1], c0))
 
+    def _exchange_start(self, plan, src, c0, nc, send_buf, halo_buf):
+        """Pack the rows the peers asked for (columns [c0, c0 + nc) of ``src``,
+        any 32-bit type) into ``send_buf`` and start their exchange into
+        ``halo_buf``; returns a handle with ``wait()`` or None."""
+        if self.comm is not None:
+            return self.comm.exchange_rows(halo_buf, send_buf, plan.recv_counts, plan.send_counts,
+                                           src=src, send_idx=plan.send_idx, col0=c0)
+        if plan.n_send:
+            self.k.gather_rows(src[:, c0:c0 + nc], plan.send_idx, send_buf)
+        return self._all_to_all_start(halo_buf, send_buf, plan.recv_counts, plan.send_counts)
+
     def _all_to_all_start(self, recv, send, recv_counts, send_counts):
-        """Start the variable-size all-to-all (rows of dim 0); returns a work
-        handle or None when it has already completed."""
+        """Start the variable-size all-to-all (rows of dim 0) of already packed
+        rows; returns a work handle or None when it has already completed."""
+        if self.comm is not None and recv.dim() == 2 and recv.element_size() == 4:
+            return self.comm.exchange_rows(recv, send, recv_counts, send_counts)
         import torch.distributed as dist
         return dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
                                       input_split_sizes=send_counts, group=self.group, async_op=True)
@@ -248,6 +266,8 @@ class FullBatchGCN(object):
 
     def _allreduce(self, t):
         if self.world > 1:
+            if self.comm is not None:
+                return self.comm.allreduce_sum_(t)
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
         return t
@@ -322,16 +342,17 @@ class FullBatchGCN(object):
             if train:
                 # the backward pass gates the halo rows of d(A P1) with the sign of
                 # the owners' H': 1 bit per element, sent while layer 2 runs
-                if plan.n_send:
-                    if self.hbits is not None:
-                        # the SpMM already wrote the sign words of every local row: pick
-                        # the requested rows (32 bytes each; a bit-preserving copy)
-                        k.gather_rows(self.hbits.view(torch.float32), plan.send_idx,
-                                      self.hbits_send[:plan.n_send].view(torch.float32))
-                    else:
+                if self.hbits is not None:
+                    # the SpMM already wrote the sign words of every local row: the
+                    # requested rows are picked (32 bytes each, a bit-preserving copy) and sent
+                    self._bits_work = self._exchange_start(
+                        plan, self.hbits.view(torch.float32), 0, self.hbits.shape[1],
+                        self.hbits_send[:plan.n_send].view(torch.float32), self.hbits_halo[:nh].view(torch.float32))
+                else:
+                    if plan.n_send:
                         k.pack_sign_bits(self.hd, rows=plan.send_idx, out=self.hbits_send[:plan.n_send])
-                self._bits_work = self._all_to_all_start(self.hbits_halo[:nh], self.hbits_send[:plan.n_send],
-                                                         plan.recv_counts, plan.send_counts)
+                    self._bits_work = self._all_to_all_start(self.hbits_halo[:nh], self.hbits_send[:plan.n_send],
+                                                             plan.recv_counts, plan.send_counts)
         else:
             self._aggregate("fwd", self.p1, self.hd, relu=True, dropout=drop,
                             sign_bits=self.hbits if (train and self.world == 1) else None)
@@ -358,10 +379,8 @@ class FullBatchGCN(object):
         dp2_work = None
         if self.recompute:
             plan = self.plan
-            if plan.n_send:
-                k.gather_rows(self.dp2, plan.send_idx, self.dp2_send[:plan.n_send])
-            dp2_work = self._all_to_all_start(self.dp2_halo[:plan.n_halo], self.dp2_send[:plan.n_send],
-                                              plan.recv_counts, plan.send_counts)
+            dp2_work = self._exchange_start(plan, self.dp2, 0, self.c, self.dp2_send[:plan.n_send],
+                                            self.dp2_halo[:plan.n_halo])
         k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
         if self.factored_bwd:

@@ -1,7 +1,8 @@
 """Halo plan of a 1-D row partition: which rows of the dense operand a shard
 must fetch from which peer, and which of its own rows each peer asks for.
 
-Rank p owns rows [p*n_loc, (p+1)*n_loc) of A_hat and of every activation.  Its
+Rank p owns a contiguous block of rows of A_hat and of every activation (blocks
+ascending with the rank; equal sizes are not required).  Its
 CSR block references some columns outside that range; only those rows (the
 halo) are exchanged before a product, with one variable-size all-to-all (RCCL
 over xGMI: every pair of GPUs exchanges its own piece concurrently on its own
@@ -47,18 +48,32 @@ class HaloPlan(object):
     def __init__(self, a_local, row_begin, n_loc, world, rank, all_to_all, plan_fn=device_halo_plan):
         """``a_local``: the local rows with GLOBAL column ids.
         ``all_to_all(recv, send, recv_counts, send_counts)`` performs a blocking
-        variable-size all-to-all along dim 0 (counts are Python lists)."""
+        variable-size all-to-all along dim 0 (counts are Python lists); it is only
+        used here, at set-up, for the row ranges and the request lists.  Ranks may
+        own different numbers of rows (N need not divide by the rank count) as long
+        as the ranges are contiguous and ascending with the rank."""
         self.world, self.rank, self.n_loc = world, rank, int(n_loc)
         self.csr, need = plan_fn(a_local, row_begin, n_loc)
         self.need = need                     # global ids of the halo rows, ascending (int32)
         dev = need.device
         self.n_halo = int(need.numel())
+        # every rank's row range, gathered with the one primitive at hand
+        mine = torch.tensor([[int(row_begin), int(n_loc)]] * world, dtype=torch.int64, device=dev)
+        ranges = torch.empty_like(mine)
+        all_to_all(ranges, mine, [1] * world, [1] * world)
+        ranges = ranges.cpu()
+        begins = [int(v) for v in ranges[:, 0].tolist()]
+        ends = [b + int(n) for b, n in zip(begins, ranges[:, 1].tolist())]
+        if begins[rank] != int(row_begin) or any(begins[p + 1] != ends[p] for p in range(world - 1)):
+            raise RuntimeError("halo plan: the ranks' row ranges are not contiguous and ascending: %s" %
+                               (list(zip(begins, ends)),))
+        self.row_ranges = list(zip(begins, ends))
         # need[] is sorted by global id, hence grouped by owner
-        edges = torch.arange(0, world + 1, dtype=torch.int64, device=dev) * int(n_loc)
+        edges = torch.tensor(begins + [ends[-1]], dtype=torch.int64, device=dev)
         bounds = torch.searchsorted(need.to(torch.int64), edges).cpu().tolist()
         self.recv_counts = [bounds[p + 1] - bounds[p] for p in range(world)]
         if self.recv_counts[rank] != 0 or sum(self.recv_counts) != self.n_halo:
-            raise RuntimeError("halo plan: inconsistent owner ranges")
+            raise RuntimeError("halo plan: a referenced row lies outside every rank's range")
         # tell every owner how many / which of its rows this rank needs
         cnt_send = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
         cnt_recv = torch.empty(world, dtype=torch.int64, device=dev)

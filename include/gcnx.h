@@ -42,7 +42,8 @@ typedef enum gcnx_status {
   GCNX_ERR_WORKSPACE = -2,    /* ws_bytes smaller than the query's answer    */
   GCNX_ERR_INDEX_RANGE = -3,  /* a coordinate outside [0,n_rows) x [0,n_cols) */
   GCNX_ERR_HIP = -4,          /* a HIP runtime call failed                   */
-  GCNX_ERR_UNSUPPORTED = -5
+  GCNX_ERR_UNSUPPORTED = -5,
+  GCNX_ERR_COMM = -6          /* an RCCL call failed                         */
 } gcnx_status;
 
 /* CSR matrix resident on the device.  Entries of a row are ordered by column,
@@ -248,6 +249,51 @@ int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
 int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                          int64_t lds, int32_t width, float *dst, int64_t ldd,
                          void *stream);
+
+/* ---- the exchange itself, over RCCL (xGMI inside a node) ------------------
+ * No counterpart in the reference (single process).  One process per GPU; every
+ * process holds one communicator for its device.  RCCL is bound at run time
+ * (dlopen), so the library also loads where RCCL is absent:
+ * gcnx_comm_available() says whether these entry points can work here.
+ * `comm` is an ncclComm_t passed as void*: either one the host already owns
+ * (ncclCommInitRank) or one made by gcnx_comm_create from the 128-byte id that
+ * rank 0 draws with gcnx_comm_unique_id and hands to every rank by any means
+ * (the Python host broadcasts it through torch.distributed).  gcnx_comm_create
+ * is collective over the ranks and binds the communicator to the CURRENT device.
+ *
+ * gcnx_halo_allgather_f32: every rank receives the rows of the dense operand
+ * that its CSR block references on other ranks (need[] of gcnx_halo_plan) and
+ * sends the rows the others asked for.  Two steps on `stream`: (1) with
+ * plan->send_idx, pack send_buf[j, 0:ncols] = local[send_idx[j], col0:col0+ncols]
+ * (send_idx NULL: send_buf already holds the packed rows); (2) one ncclSend /
+ * ncclRecv per peer inside one group, so that all pairs of GPUs exchange
+ * concurrently, each over its own link.  halo receives h_recv_rows[p] rows of
+ * ncols floats from peer p = 0, 1, ..., world-1 in that order, which is the
+ * order of need[] (sorted by global row id, hence grouped by owner).  Rows are
+ * moved as bytes: 32-bit sign words travel through the same call.  Asynchronous
+ * and stream-ordered like the compute entry points: issue it on a stream of its
+ * own to overlap it with compute and order the two with events.  Calls on one
+ * communicator must be issued in the same order on every rank.
+ * gcnx_comm_allreduce_sum_f32: in-place sum over the ranks (weight gradients,
+ * loss). */
+#define GCNX_COMM_ID_BYTES 128
+typedef struct gcnx_halo_exchange {
+  int32_t world;              /* ranks of the communicator                     */
+  int32_t rank;               /* this rank                                     */
+  const int64_t *h_send_rows; /* HOST [world]: rows this rank sends to peer p  */
+  const int64_t *h_recv_rows; /* HOST [world]: rows it receives from peer p    */
+  const int32_t *send_idx;    /* DEVICE [sum h_send_rows]: local row of every
+                                 row to send, grouped by destination; nullable */
+} gcnx_halo_exchange;
+int gcnx_comm_available(void);
+int gcnx_comm_unique_id(void *id_out /* GCNX_COMM_ID_BYTES, host */);
+int gcnx_comm_create(int32_t world, int32_t rank, const void *id, void **comm_out);
+int gcnx_comm_destroy(void *comm);
+int gcnx_halo_allgather_f32(const gcnx_halo_exchange *plan, void *comm,
+                            const float *local, int64_t ld_local, int64_t col0,
+                            int32_t ncols, float *send_buf, float *halo,
+                            void *stream);
+int gcnx_comm_allreduce_sum_f32(void *comm, float *buf, int64_t n, void *stream);
 
 /* Measurement hook (no counterpart in the reference): while set, every SpMM
  * call made by this thread records hipEvent `start` right before its first

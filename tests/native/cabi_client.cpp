@@ -196,6 +196,42 @@ int main() {
     if (gcnx_spmm_csr_factored_f32(&a, d_chunk, d_d, 8, d_bits, words, nullptr, 0, nullptr, 0, n_cols, d_w, 8, 1, 8,
                                    2.0f, d_fc, fw, fw, f_ws, f_bytes, stream) != GCNX_ERR_UNSUPPORTED) return 1;
   }
+  // ---- halo exchange over RCCL, driven from this process alone ------------------
+  // One rank (RCCL refuses two ranks on one GPU): the id, the communicator, the
+  // packed send and the grouped send / receive are the calls a multi-process host
+  // makes, here with this rank as its own peer.
+  if (gcnx_comm_available()) {
+    char id[GCNX_COMM_ID_BYTES];
+    void *comm = nullptr;
+    GCNX_OK_(gcnx_comm_unique_id(id));
+    GCNX_OK_(gcnx_comm_create(1, 0, id, &comm));
+    const int64_t n_ask = 1500;
+    std::vector<int32_t> ask(n_ask);
+    for (auto &v : ask) v = (int32_t)(rnd() % n_cols);
+    int32_t *d_ask = dev_alloc<int32_t>(n_ask);
+    float *d_send = dev_alloc<float>((size_t)n_ask * 16), *d_halo = dev_alloc<float>((size_t)n_ask * 16);
+    if (!d_ask || !d_send || !d_halo) return 2;
+    HIP_OK(hipMemcpy(d_ask, ask.data(), n_ask * 4, hipMemcpyHostToDevice));
+    const int64_t rows[1] = {n_ask};
+    gcnx_halo_exchange plan = {1, 0, rows, rows, d_ask};
+    // columns [32, 48) of the rows of b that "the peer" asked for
+    GCNX_OK_(gcnx_halo_allgather_f32(&plan, comm, d_b, width, 32, 16, d_send, d_halo, stream));
+    float one_val = 3.0f, *d_one = dev_alloc<float>(1);
+    HIP_OK(hipMemcpyAsync(d_one, &one_val, 4, hipMemcpyHostToDevice, stream));
+    GCNX_OK_(gcnx_comm_allreduce_sum_f32(comm, d_one, 1, stream));
+    std::vector<float> halo((size_t)n_ask * 16);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(halo.data(), d_halo, halo.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&one_val, d_one, 4, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < n_ask; ++j)
+      for (int cidx = 0; cidx < 16; ++cidx)
+        if (halo[(size_t)j * 16 + cidx] != b[(size_t)ask[j] * width + 32 + cidx]) return 1;
+    if (one_val != 3.0f) return 1;
+    GCNX_OK_(gcnx_comm_destroy(comm));
+    std::printf("halo exchange over RCCL (1 rank): %lld rows x 16 columns delivered\n", (long long)n_ask);
+  } else {
+    std::printf("RCCL not available here: halo exchange skipped (%s)\n", gcnx_last_error());
+  }
   std::printf("C ABI client OK (abi %d)\n", gcnx_abi_version());
   return 0;
 }

@@ -34,13 +34,20 @@ def _problem(scale=7, f=12, hidden=16, classes=5):
 
 
 def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5,
-         classes=5):
+         classes=5, uneven=False):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(hidden=hidden, classes=classes)
-    n_loc = n // world
-    rb, re_ = rank * n_loc, (rank + 1) * n_loc
+    if uneven:
+        # row ranges of different sizes (N does not divide by the rank count)
+        cuts = [0] + [int(round((p + 1) * n / world + (3 if p % 2 == 0 and p + 1 < world else 0)))
+                      for p in range(world)]
+        cuts[-1] = n
+        rb, re_ = cuts[rank], cuts[rank + 1]
+    else:
+        n_loc = n // world
+        rb, re_ = rank * n_loc, (rank + 1) * n_loc
     T = torch.from_numpy
     eng = engine.FullBatchGCN(
         CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
@@ -93,6 +100,27 @@ def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden, classes)
     np.testing.assert_allclose(r0["w1"], one["w1"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
     z = np.concatenate([np.load(os.path.join(out, "w%d_r%d.npz" % (world, r)))["z"] for r in range(world)])
+    np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
+
+
+@pytest.mark.parametrize("world,halo_mode,hidden", [(3, "exchange", 16), (2, "recompute", 32), (3, "recompute", 32)])
+def test_uneven_row_ranges(tmp_path, world, halo_mode, hidden):
+    """Ranks that own different numbers of rows (three ranks over 128 rows; two
+    ranks cut at 67): the halo plan takes the owners' ranges from the ranks
+    themselves instead of assuming equal blocks."""
+    out = str(tmp_path)
+    _run(0, 1, 0, None, out, "auto", hidden)
+    mp.spawn(_run, args=(world, _free_port(), 8, out, halo_mode, hidden, "reference", "", 0.5, 5, True),
+             nprocs=world, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    parts = [np.load(os.path.join(out, "w%d_r%d.npz" % (world, r))) for r in range(world)]
+    assert len(set(p["z"].shape[0] for p in parts)) > 1          # the split really is uneven
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["w1"], p["w1"]) and np.array_equal(parts[0]["outs"], p["outs"])
+    np.testing.assert_allclose(parts[0]["outs"], one["outs"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(parts[0]["ev"], one["ev"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(parts[0]["w1"], one["w1"], rtol=0, atol=2e-6)
+    z = np.concatenate([p["z"] for p in parts])
     np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
 
 

@@ -205,3 +205,85 @@ def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden, 
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["halo_mode"] == halo_mode
     assert abs(j1["final_xent"] - j2["final_xent"]) <= 1e-5 * abs(j1["final_xent"])
     assert abs(j1["final_train_acc"] - j2["final_train_acc"]) <= 1e-6
+
+
+def _comm_worker(out_path):
+    """Runs in a child process: a one-rank RCCL communicator created through the
+    C ABI, rows exchanged with itself through gcnx_halo_allgather_f32."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from gcn_amd import _lib
+    from gcn_amd.comm import RcclComm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=0, world_size=1)      # only carries the communicator id
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    comm = RcclComm(dist.group.WORLD, 1, 0, dev)
+    res = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    src = torch.rand((5000, 48), device=dev, generator=g)
+    idx = torch.randint(0, 5000, (1234,), device=dev, generator=g).to(torch.int32)
+    # (1) packed by the call: columns [16, 32) of the rows in idx, sent to "peer" 0 (itself)
+    send = torch.empty((1234, 16), device=dev)
+    recv = torch.full((1234, 16), float("nan"), device=dev)
+    # the operand is produced on the compute stream right before: the exchange must order itself behind it
+    src2 = src * 2.0
+    h = comm.exchange_rows(recv, send, [1234], [1234], src=src2, send_idx=idx, col0=16)
+    h.wait()
+    want = src2[idx.long(), 16:32]
+    res["gathered_equal"] = bool(torch.equal(recv, want))
+    # (2) already packed 32-bit words (sign words travel as bytes, NaN patterns included)
+    words = torch.randint(-2 ** 31, 2 ** 31 - 1, (777, 8), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    got = torch.zeros_like(words)
+    comm.exchange_rows(got.view(torch.float32), words.view(torch.float32), [777], [777]).wait()
+    res["words_equal"] = bool(torch.equal(got, words))
+    # (3) nothing to trade is a no-op, and a wrong plan is a status, not a hang
+    comm.exchange_rows(torch.empty((0, 4), device=dev), torch.empty((0, 4), device=dev), [0], [0]).wait()
+    try:
+        comm.exchange_rows(recv, send, [1234, 0], [1234, 0])
+        res["bad_counts"] = "accepted"
+    except ValueError:
+        res["bad_counts"] = "ValueError"
+    import ctypes as C
+    two = (C.c_int64 * 2)(1234, 0)
+    plan = _lib.HaloExchangeStruct(2, 0, two, two, None)          # a plan for 2 ranks on a 1-rank communicator
+    rc = _lib.load().gcnx_halo_allgather_f32(C.byref(plan), comm._comm, None, 0, 0, 16, C.c_void_p(send.data_ptr()),
+                                             C.c_void_p(recv.data_ptr()), None)
+    res["bad_plan"] = int(rc)
+    # (4) sum over one rank leaves the tensor as it is
+    t = torch.rand(65536, device=dev, generator=g)
+    keep = t.clone()
+    comm.allreduce_sum_(t)
+    torch.cuda.synchronize()
+    res["allreduce_equal"] = bool(torch.equal(t, keep))
+    comm.close()
+    dist.destroy_process_group()
+    with open(out_path, "w") as fh:
+        json.dump(res, fh)
+
+
+def test_cabi_rccl_exchange_single_rank(tmp_path):
+    """The RCCL path of the C ABI on the hardware at hand (one GPU): dlopen of
+    librccl.so from inside libgcnhip.so, communicator from a broadcast id, the
+    grouped send / receive with the gather in front of it, stream ordering against
+    the compute stream, the all-reduce.  More ranks need more GPUs (RCCL refuses
+    two ranks on one device); the multi-rank bookkeeping is covered by the gloo
+    tests."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = str(tmp_path / "comm.json")
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_engine as t; t._comm_worker(%r)" % (
+        root, os.path.dirname(os.path.abspath(__file__)), out)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150, cwd=root)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    res = json.load(open(out))
+    assert res == {"gathered_equal": True, "words_equal": True, "bad_counts": "ValueError", "bad_plan": -1,
+                   "allreduce_equal": True}, res
