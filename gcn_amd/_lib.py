@@ -76,6 +76,7 @@ SIGNATURES = {
     "gcnx_spmm_factored_supported": (_int, [_i32, _i32]),
     "gcnx_spmm_csr_factored_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _int,
                                           _i32, _f32, _p, _i64, _i32, _p, _sz, _p]),
+    "gcnx_dense_arith": (_int, [_int]),
     "gcnx_gemm_dropout_a_supported": (_int, [_int, _int, _i64, _i64, _i64]),
     "gcnx_gemm_dropout_a_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _i64,
                                        _f32, _f32, _p, _sz, _p]),

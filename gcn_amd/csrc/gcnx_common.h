@@ -13,6 +13,9 @@ namespace gcnx {
 void set_error(const char *fmt, ...);
 const char *get_error();
 
+// Arithmetic of the large dense products on this thread (gcnx_dense_arith).
+int dense_arith_mode();
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int kWave = 64;            // gfx950 wavefront

@@ -81,7 +81,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs &g, float acc, flo
                                                int64_t gn) {
   float out = g.alpha * acc;
   if (g.beta != 0.0f) out += g.beta * *dst;
-  if (g.relu) out = fmaxf(out, 0.0f);
+  if (g.relu && out < 0.0f) out = 0.0f;   // a NaN stays a NaN
   if (g.gate) out = g.gate[gm * g.ldgate + gn] > 0.0f ? out * g.gate_scale : 0.0f;
   if (g.gate_bits) out = ((g.gate_bits[gm * g.ldbits + (gn >> 5)] >> (gn & 31)) & 1u) ? out * g.gate_scale : 0.0f;
   return out;
@@ -240,6 +240,59 @@ __device__ __forceinline__ void store_tile_relu_dropout(const GemmArgs &g, const
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// Epilogue shared by the tall MFMA kernels: accumulator tiles of one wavefront
+// (TM_W x TN_W tiles of 32 x 32, tile (i, t) at rows (wm * TM_W + i) * 32, columns
+// (wn * TN_W + t) * 32 of the BM x BN block tile) -> C.  `smem` is the block's
+// staging memory, free once the K loop has ended (one 32 x 36-word tile per
+// wavefront is used by the output-dropout path).
+template <int TM_W, int TN_W, int BM, int BN>
+__device__ __forceinline__ void store_acc_tiles(const GemmArgs &g, const f16v (&acc)[TM_W * TN_W], float *smem,
+                                                int w, int wm, int wn, int lane, int64_t m0, int64_t n0) {
+  constexpr int NT = TM_W * TN_W;
+  constexpr int kTilePitch = 36;
+  const int li = lane & 31, lk = lane >> 5;
+  // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  if (g.odrop_vec) {
+    // Output dropout: the tile is turned through LDS so that a lane holds four
+    // consecutive columns = one Philox block, and stores 16 bytes.
+    float *const my = smem + w * (32 * kTilePitch);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      store_tile_relu_dropout(g, acc[t], my, kTilePitch, lane, m0 + (wm * TM_W + t / TN_W) * 32,
+                              n0 + (wn * TN_W + t % TN_W) * 32);
+    return;
+  }
+  if (g.beta == 0.0f && !g.gate && !g.gate_bits && m0 + BM <= g.M && n0 + BN <= g.N) {
+    // whole block tile in range, plain epilogue: wavefront-uniform base per (row,
+    // tile) plus one per-lane offset, no per-element conditions.  relu is a
+    // compare-and-select, so that a NaN accumulator stays NaN in either case (as it
+    // does in the per-element epilogue below).
+    const int c_off = 4 * lk * (int)g.ldc + li;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float *const base = g.C + (m0 + (wm * TM_W + t / TN_W) * 32) * g.ldc + n0 + (wn * TN_W + t % TN_W) * 32;
+#pragma unroll
+      for (int rgi = 0; rgi < 16; ++rgi) {
+        const float v = g.alpha * acc[t][rgi];
+        (base + ((rgi & 3) + 8 * (rgi >> 2)) * g.ldc)[c_off] = (g.relu && v < 0.0f) ? 0.0f : v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int rgi = 0; rgi < 16; ++rgi) {
+      const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
+      const int64_t gm = m0 + (wm * TM_W + t / TN_W) * 32 + row;
+      const int64_t gn = n0 + (wn * TN_W + t % TN_W) * 32 + li;
+      if (gm >= g.M || gn >= g.N) continue;
+      float *dst = g.C + gm * g.ldc + gn;
+      *dst = gemm_epilogue(g, acc[t][rgi], dst, gm, gn);
+    }
+  }
+}
+
 // BN = 128 / 256: wavefront w owns rows [32w, 32w+32) and all BN columns (four
 // or eight accumulator tiles); 256 is used when N allows it, so that A is
 // streamed (and its fused dropout regenerated) once per 256 output columns.  BN = 32: the class-dimension / skinny case (N <= 32,
@@ -383,43 +436,162 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
     }
     __syncthreads();
   }
-  // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-  if (g.odrop_vec) {
-    // Output dropout: the tile is turned through LDS so that a lane holds four
-    // consecutive columns = one Philox block, and stores 16 bytes.
-    float *const my = smem + w * (32 * kTilePitch);
+  store_acc_tiles<TM_W, TN_W, MB, BN>(g, acc, smem, w, wm, wn, lane, m0, n0);
+}
+
+// ---------------------------------------------------------------------------
+// The tall product on the bf16 matrix pipe at fp32 accuracy ("bf16 x 3").
+//
+// On gfx950 the f32-input MFMA runs at the fp32 VECTOR rate (64 FLOP/clk/SIMD,
+// 1/16 of the bf16 MFMA) and does not overlap with vector instructions, so an
+// fp32 product on it is bound by the vector ALUs.  Here every fp32 operand x is
+// split EXACTLY into three bf16 pieces, x = h + m + l (three times 8 significant
+// bits = the 24 of an fp32: h = the top 16 bits of x, m = the top 16 bits of
+// x - h, l = x - h - m, all subtractions exact), and a product a * b is formed
+// from the six partial products of weight >= 2^-16,
+//     ah*bh + am*bh + al*bh + ah*bm + am*bm + ah*bl,
+// each one exact in fp32 (8 x 8 significant bits), accumulated in fp32 inside
+// v_mfma_f32_32x32x16_bf16.  What is dropped (am*bl + al*bm + al*bl) is below
+// 2^-23 of |a*b|, the size of the rounding of one fp32 product.  Six bf16 MFMAs of 32
+// cycles replace eight f32 MFMAs of 64 cycles per 16 values of k, and they
+// co-execute with the vector instructions (Philox, splitting, addressing).
+//
+// Block tile 128 x 256, wavefronts 2 x 2 each 64 x 128 (8 accumulator tiles), K
+// step 16 = one MFMA.  LDS holds the three pieces of the A tile [m][16 k] and of
+// the B tile [n][16 k] as bf16 rows of 32 bytes on a 48-byte pitch (16-byte
+// fragment reads of 16 consecutive rows then fall on 16 different bank groups).
+// A is split while it is staged (after its fused dropout); B -- the weights -- is
+// split once by split_b_kernel into the workspace, laid out so that the B tile of
+// a K step is one contiguous block: Bsp[k / 16][piece][n][k % 16].
+// ---------------------------------------------------------------------------
+typedef __bf16 __attribute__((ext_vector_type(8))) bf8v;
+typedef int __attribute__((ext_vector_type(4))) i4v;
+typedef unsigned __attribute__((ext_vector_type(2))) u2v;
+
+// x = h + m + l exactly; each piece is a bf16 held in the upper half of a word
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(h);
+  m = __float_as_uint(r) & 0xffff0000u;
+  l = __float_as_uint(r - __uint_as_float(m));   // at most 8 significant bits: its lower half is zero
+}
+// two upper halves -> one word (lo in bits 0..15)
+__device__ __forceinline__ unsigned pack_upper(unsigned lo, unsigned hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+
+constexpr int kSplitPitch = 48;   // bytes between the 32-byte rows of a split tile in LDS
+
+__global__ __launch_bounds__(kBlock) void split_b_kernel(const float *__restrict__ B, int64_t ldb, int trans_b,
+                                                         int64_t K, int64_t N, unsigned short *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= K * N) return;
+  // thread e -> (k / 16, n, k % 16): writes are contiguous per piece
+  const int kk = (int)(e & 15);
+  const int64_t n = (e >> 4) % N, ks = (e >> 4) / N;
+  const int64_t k = ks * 16 + kk;
+  const float x = trans_b ? B[n * ldb + k] : B[k * ldb + n];
+  unsigned h, m, l;
+  split3(x, h, m, l);
+  const int64_t base = (ks * 3 * N + n) * 16 + kk;
+  out[base] = (unsigned short)(h >> 16);
+  out[base + N * 16] = (unsigned short)(m >> 16);
+  out[base + 2 * N * 16] = (unsigned short)(l >> 16);
+}
+
+__global__ __launch_bounds__(kBlock, 2) void gemm_split_nn_kernel(const GemmArgs g,
+                                                                  const unsigned short *__restrict__ Bsp) {
+  constexpr int BM = 128, BN = 256, KB = 16, P = kSplitPitch;
+  constexpr int kABytes = 3 * BM * P, kBBytes = 3 * BN * P;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kABytes + kBBytes];
+  unsigned char *const As = smem;
+  unsigned char *const Bs = smem + kABytes;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int li = lane & 31, lk = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  f16v acc[8];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      store_tile_relu_dropout(g, acc[t], my, kTilePitch, lane, m0 + (wm * TM_W + t / TN_W) * 32,
-                              n0 + (wn * TN_W + t % TN_W) * 32);
-    return;
-  }
-  if (g.beta == 0.0f && !g.gate && !g.gate_bits && m0 + MB <= g.M && n0 + BN <= g.N) {
-    // whole block tile in range, plain epilogue: wavefront-uniform base per (row,
-    // tile) plus one per-lane offset, no per-element conditions
-    const int c_off = 4 * lk * (int)g.ldc + li;
-    const float lo = g.relu ? 0.0f : -__builtin_inff();
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float *const base = g.C + (m0 + (wm * TM_W + t / TN_W) * 32) * g.ldc + n0 + (wn * TN_W + t % TN_W) * 32;
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  // staging registers: the next K step's tiles travel here while this step's MFMAs run
+  f4v ra[2];
+  i4v rb[6];
+  auto load_tiles = [&](int64_t kk) {
 #pragma unroll
-      for (int rgi = 0; rgi < 16; ++rgi)
-        (base + ((rgi & 3) + 8 * (rgi >> 2)) * g.ldc)[c_off] = fmaxf(g.alpha * acc[t][rgi], lo);
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int m = e >> 2, q = e & 3;
+      const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;   // rows past the end: never stored
+      ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
     }
-    return;
-  }
+    // B tile of this K step: pieces p = 0..2, rows n0 .. n0+255, 32 bytes each
+    const unsigned short *src = Bsp + ((kk >> 4) * 3 * g.N + n0) * 16;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int rgi = 0; rgi < 16; ++rgi) {
-      const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk;
-      const int64_t gm = m0 + (wm * TM_W + t / TN_W) * 32 + row;
-      const int64_t gn = n0 + (wn * TN_W + t % TN_W) * 32 + li;
-      if (gm >= g.M || gn >= g.N) continue;
-      float *dst = g.C + gm * g.ldc + gn;
-      *dst = gemm_epilogue(g, acc[t][rgi], dst, gm, gn);
+    for (int i = 0; i < 6; ++i) {
+      const int e = tid + i * kBlock;              // 16-byte piece: (p, n, half)
+      rb[i] = *reinterpret_cast<const i4v *>(src + (int64_t)(e >> 9) * g.N * 16 + (e & 511) * 8);
     }
+  };
+  auto store_tiles = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int m = e >> 2, q = e & 3;
+      f4v v = ra[i];
+      if (g.adrop_keep < 1.0f) {
+        const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;
+        v = drop4(g, v, g.adrop_rows ? (int64_t)g.adrop_rows[gm] : gm, kk + q * 4);
+      }
+      unsigned h[4], md[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(v[j], h[j], md[j], l[j]);
+      unsigned char *d = As + m * P + q * 8;
+      *reinterpret_cast<u2v *>(d) = u2v{pack_upper(h[0], h[1]), pack_upper(h[2], h[3])};
+      *reinterpret_cast<u2v *>(d + BM * P) = u2v{pack_upper(md[0], md[1]), pack_upper(md[2], md[3])};
+      *reinterpret_cast<u2v *>(d + 2 * BM * P) = u2v{pack_upper(l[0], l[1]), pack_upper(l[2], l[3])};
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int e = tid + i * kBlock;
+      const int rest = e & 511;
+      *reinterpret_cast<i4v *>(Bs + (e >> 9) * (BN * P) + (rest >> 1) * P + (rest & 1) * 16) = rb[i];
+    }
+  };
+  const unsigned char *const a_frag = As + ((wm * 2) * 32 + li) * P + lk * 16;
+  const unsigned char *const b_frag = Bs + ((wn * 4) * 32 + li) * P + lk * 16;
+  load_tiles(0);
+  for (int64_t kk = 0; kk < g.K; kk += KB) {
+    store_tiles(kk);
+    __syncthreads();
+    if (kk + KB < g.K) load_tiles(kk + KB);
+    i4v af[2][3];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[tm][p] = *reinterpret_cast<const i4v *>(a_frag + p * (BM * P) + tm * 32 * P);
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb) {
+      i4v bf[4];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) bf[tn] = *reinterpret_cast<const i4v *>(b_frag + pb * (BN * P) + tn * 32 * P);
+#pragma unroll
+      for (int pa = 0; pa + pb < 3; ++pa)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            acc[tm * 4 + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf8v, af[tm][pa]), __builtin_bit_cast(bf8v, bf[tn]), acc[tm * 4 + tn], 0, 0, 0);
+    }
+    __syncthreads();
   }
+  store_acc_tiles<2, 4, BM, BN>(g, acc, reinterpret_cast<float *>(smem), w, wm, wn, lane, m0, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -552,6 +724,142 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_tn_kernel(
           *dst = gemm_epilogue(g, acc[a][b][rgi], dst, gm, gn);
         }
       }
+}
+
+// ---------------------------------------------------------------------------
+// The weight gradient  C[M,N] = A^T * B  (A stored [K, M], B stored [K, N], K =
+// the node dimension, split over grid.z) on the bf16 matrix pipe with exactly
+// split operands, as gemm_split_nn_kernel.  Both operands are node-major, i.e.
+// k-major, while a lane of v_mfma_f32_32x32x16_bf16 wants 8 consecutive k of ONE
+// column: the tiles are stored in LDS as they lie in memory ([k][m], [k][n], bf16)
+// and read with ds_read_b64_tr_b16, which hands each lane of a 16-lane group one
+// column of a 4 (k) x 16 block.  Row pitch = row bytes + 64, so the four k rows a
+// 32-lane half reads at once fall on four different quarters of the 64 banks.
+// Block tile 128 x 256, wavefronts 2 x 2 each 64 x 128, K step 16.
+// ---------------------------------------------------------------------------
+typedef short __attribute__((ext_vector_type(4))) s4v;
+typedef short __attribute__((ext_vector_type(8))) s8v;
+
+__device__ __forceinline__ bf8v tr_frag(const unsigned char *p, int row_pitch) {
+  // rows k .. k+3 at p, rows k+4 .. k+7 four rows further down
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v *)(p));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v *)(p + 4 * row_pitch));
+  const s8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf8v, v);
+}
+
+__global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs g) {
+  constexpr int BM = 128, BN = 256, BK = 16;
+  constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;           // row pitches in bytes
+  constexpr int kAPiece = BK * PA, kBPiece = BK * PB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kAPiece + 3 * kBPiece];
+  unsigned char *const As = smem;
+  unsigned char *const Bs = smem + 3 * kAPiece;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int li = lane & 31, lk = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  f16v acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+  f4v ra[2], rb[4];
+  auto load_tiles = [&](int64_t kk) {
+    const bool whole = kk + BK <= kend;     // all but possibly the last K step of a split
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      ra[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (whole || kk + k < kend) ra[i] = *reinterpret_cast<const f4v *>(g.A + (kk + k) * g.lda + m0 + q * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 6, q = e & 63;
+      rb[i] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      if (whole || kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
+    }
+  };
+  auto put3 = [&](unsigned char *d, int piece_bytes, f4v v) {
+    unsigned h[4], md[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(v[j], h[j], md[j], l[j]);
+    *reinterpret_cast<u2v *>(d) = u2v{pack_upper(h[0], h[1]), pack_upper(h[2], h[3])};
+    *reinterpret_cast<u2v *>(d + piece_bytes) = u2v{pack_upper(md[0], md[1]), pack_upper(md[2], md[3])};
+    *reinterpret_cast<u2v *>(d + 2 * piece_bytes) = u2v{pack_upper(l[0], l[1]), pack_upper(l[2], l[3])};
+  };
+  auto store_tiles = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      f4v v = ra[i];
+      if (g.adrop_keep < 1.0f) v = drop4(g, v, kk + k, m0 + q * 4);   // rows past kend hold zeros
+      put3(As + k * PA + q * 8, kAPiece, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 6, q = e & 63;
+      put3(Bs + k * PB + q * 8, kBPiece, rb[i]);
+    }
+  };
+  // transposed-read address of this lane inside a 32-column operand tile: lane
+  // 4q + p of a 16-lane group supplies row q, columns 4p .. 4p+3 of its block;
+  // groups 0, 1 take k 0..7 of columns 0..15 / 16..31, groups 2, 3 k 8..15
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int a_tr = ((grp >> 1) * 8 + gq) * PA + ((wm * 2) * 32 + (grp & 1) * 16 + gp * 4) * 2;
+  const int b_tr = ((grp >> 1) * 8 + gq) * PB + ((wn * 4) * 32 + (grp & 1) * 16 + gp * 4) * 2;
+  (void)li; (void)lk;
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int64_t kk = kbeg; kk < kend; kk += BK) {
+    store_tiles(kk);
+    __syncthreads();
+    if (kk + BK < kend) load_tiles(kk + BK);
+    bf8v af[2][3];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[tm][p] = tr_frag(As + p * kAPiece + a_tr + tm * 64, PA);
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb) {
+      bf8v bf[4];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) bf[tn] = tr_frag(Bs + pb * kBPiece + b_tr + tn * 64, PB);
+#pragma unroll
+      for (int pa = 0; pa + pb < 3; ++pa)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            acc[tm * 4 + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm][pa], bf[tn], acc[tm * 4 + tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int lk2 = lane >> 5, li2 = lane & 31;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int rgi = 0; rgi < 16; ++rgi) {
+      const int row = (rgi & 3) + 8 * (rgi >> 2) + 4 * lk2;
+      const int64_t gm = m0 + (wm * 2 + t / 4) * 32 + row;
+      const int64_t gn = n0 + (wn * 4 + t % 4) * 32 + li2;
+      if (gm >= g.M || gn >= g.N) continue;
+      if (g.splits > 1) {
+        g.partial[((int64_t)blockIdx.z * g.M + gm) * g.N + gn] = acc[t][rgi];
+      } else {
+        float *dst = g.C + gm * g.ldc + gn;
+        *dst = gemm_epilogue(g, acc[t][rgi], dst, gm, gn);
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -995,6 +1303,12 @@ static int launch_split_reduce(GemmArgs g, hipStream_t st) {
   return GCNX_OK;
 }
 
+// Shapes served by gemm_split_nn_kernel (plain A; B plain or transposed).
+static bool nn_split_shape(int64_t M, int64_t N, int64_t K) {
+  return M >= 4 * 128 && K % 16 == 0 && K >= 64 && N % 256 == 0;
+}
+static size_t nn_split_ws_bytes(int64_t N, int64_t K) { return (size_t)K * (size_t)N * 3 * sizeof(unsigned short); }
+
 }  // namespace gcnx
 
 using namespace gcnx;
@@ -1008,7 +1322,9 @@ extern "C" size_t gcnx_gemm_workspace_bytes(int trans_a, int trans_b, int64_t M,
   int s = choose_splits(M, N, K);
   if (trans_a && !trans_b && skinny_tn_shape(M, N, K)) s = std::max(s, skinny_tn_splits(M, K));
   if (trans_a && !trans_b && tn_mfma_shape(M, N, K)) s = std::max(s, tn_mfma_splits(M, N, K));
-  return split_ws_bytes(s, M, N);
+  size_t bytes = split_ws_bytes(s, M, N);
+  if (!trans_a && nn_split_shape(M, N, K)) bytes = std::max(bytes, nn_split_ws_bytes(N, K));
+  return bytes;
 }
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float *A,
@@ -1241,6 +1557,19 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
     const int64_t mt = ceil_div(M, MB);
     GCNX_REQUIRE(mt <= 0x7fffffffll && N / 128 <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
+    if (dense_arith_mode() == 0 && nn_split_shape(M, N, K) && K * N / kBlock < 0x7fffffffll) {
+      // exactly split operands on the bf16 matrix pipe; the weights are split first
+      const size_t need = nn_split_ws_bytes(N, K);
+      GCNX_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GCNX_ERR_WORKSPACE,
+                   "gemm: workspace of %zu bytes (16-byte aligned) required, got %zu", need, ws_bytes);
+      unsigned short *bsp = static_cast<unsigned short *>(ws);
+      hipLaunchKernelGGL(split_b_kernel, dim3((unsigned)ceil_div(K * N, kBlock)), dim3(kBlock), 0, st, B, ldb, trans_b,
+                         K, N, bsp);
+      GCNX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(gemm_split_nn_kernel, dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g, bsp);
+      GCNX_CHECK_LAUNCH();
+      return GCNX_OK;
+    }
     if (N % 256 == 0 && !trans_b) {
       // the whole 256-column slab per workgroup: A (and its dropout) is read once per slab
       hipLaunchKernelGGL((gemm_mfma_kernel<256, false>), dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g);
@@ -1271,7 +1600,11 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
       g.splits = sp;
       g.k_per_split = ceil_div(ceil_div(K, sp), 16) * 16;
     }
-    if (N % 256 == 0) {
+    if (N % 256 == 0 && dense_arith_mode() == 0) {
+      // exactly split operands on the bf16 matrix pipe
+      hipLaunchKernelGGL(gemm_split_tn_kernel, dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
+                         dim3(kBlock), 0, st, g);
+    } else if (N % 256 == 0) {
       // 128 x 256 tiles: each workgroup reads its slice of A (and regenerates its
       // dropout) once per 256 output columns
       hipLaunchKernelGGL((gemm_mfma_tn_kernel<256>), dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),

@@ -424,7 +424,42 @@ typedef uint32_t __attribute__((ext_vector_type(4))) u4v;
 
 // NT: 32-column tiles per wavefront (a slab of 32 NT columns per blockIdx.y);
 // FULL: the width is a multiple of the slab, no tile needs a bounds check.
-template <int NT, bool FULL>
+//
+// SPLIT: the row-forming runs on the bf16 matrix pipe at fp32 accuracy instead of
+// the f32-input MFMA (which runs at the vector rate and does not overlap with the
+// vector instructions of the update): D rows and weights are split exactly into
+// three bf16 pieces each, x = h + m + l, and T is the sum of the six partial
+// products of weight >= 2^-16 (what is dropped is below 2^-23 of each product, one
+// fp32 rounding), six v_mfma_f32_32x32x16_bf16 per tile instead of eight chained
+// v_mfma_f32_32x32x2_f32.  The top pieces of the weights stay in registers, the
+// two lower ones are shared by the workgroup's wavefronts through LDS.  Results
+// then agree with the two-kernel path to fp32 rounding, not to the bit.
+typedef __bf16 __attribute__((ext_vector_type(8))) bf8s;
+typedef int __attribute__((ext_vector_type(4))) i4s;
+
+__device__ __forceinline__ void split3f(float x, unsigned &h, unsigned &m, unsigned &l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(h);
+  m = __float_as_uint(r) & 0xffff0000u;
+  l = __float_as_uint(r - __uint_as_float(m));   // at most 8 significant bits: its lower half is zero
+}
+__device__ __forceinline__ int pack_up(unsigned lo, unsigned hi) {
+  return (int)__builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// eight fp32 values (consecutive k) -> the three bf16 operands of one lane
+__device__ __forceinline__ void split8(const float (&x)[8], i4s &oh, i4s &om, i4s &ol) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3f(x[j], h[j], m[j], l[j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    oh[j] = pack_up(h[2 * j], h[2 * j + 1]);
+    om[j] = pack_up(m[2 * j], m[2 * j + 1]);
+    ol[j] = pack_up(l[2 * j], l[2 * j + 1]);
+  }
+}
+
+template <int NT, bool FULL, bool SPLIT>
 __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const SpmmArgs a) {
   constexpr int HW = 32;     // lanes per half
   const int lane = threadIdx.x & (kWave - 1);
@@ -435,15 +470,37 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
   const int cbase = (int)blockIdx.y * (NT * 32);
   const int nt = FULL ? NT : ((a.width - cbase) / 32 < NT ? (a.width - cbase) / 32 : NT);
 
-  // op(W) fragments: B[k][j] of tile t, k fed in the order of gemm_small_k_mfma_kernel
-  float bf[NT][8];
+  // op(W) fragments: B[k][j] of tile t.  Exact form: k fed in the order of
+  // gemm_small_k_mfma_kernel.  Split form: lane (li, h) holds k = 8 h .. 8 h + 7 of
+  // column li of its tile, as three bf16 operands; the top one stays in registers,
+  // the two lower ones go to LDS (one copy for the four wavefronts).
+  float bf[SPLIT ? 1 : NT][8];
+  i4s bh[SPLIT ? NT : 1];
+  __shared__ __attribute__((aligned(16))) i4s wlow[SPLIT ? 2 * NT * kWave : 1];
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int sx = 0; sx < 8; ++sx) {
-      const int k = 8 * (sx >> 2) + 4 * h + (sx & 3);
-      bf[t][sx] = t < nt ? a.Wm[k * a.w_sk + (int64_t)(cbase + 32 * t + li) * a.w_sj] : 0.0f;
+      for (int sx = 0; sx < 8; ++sx) {
+        const int k = 8 * (sx >> 2) + 4 * h + (sx & 3);
+        bf[t][sx] = t < nt ? a.Wm[k * a.w_sk + (int64_t)(cbase + 32 * t + li) * a.w_sj] : 0.0f;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        x[k] = t < nt ? a.Wm[(8 * h + k) * a.w_sk + (int64_t)(cbase + 32 * t + li) * a.w_sj] : 0.0f;
+      i4s om, ol;
+      split8(x, bh[t], om, ol);
+      if (threadIdx.x < kWave) {      // every wavefront computes the same fragments: one writes
+        wlow[t * kWave + lane] = om;
+        wlow[(NT + t) * kWave + lane] = ol;
+      }
     }
+    __syncthreads();
+  }
 
   const int chunk = a.chunk;
   const int64_t n0 = live ? ch * (int64_t)chunk : 0;
@@ -514,12 +571,16 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
       if (k0 >= nk_max) break;
       // A fragments: D row of nonzero (ah, an) of this round, k = 4 h .. and 8 + 4 h ..
       float af[8];
+      i4s a_h, a_m, a_l;
       {
         const int cc = __shfl(cols, ah * HW + 16 * sb + an, kWave);
         const float *drow = cc < a.split ? a.D + (int64_t)cc * a.ldd : a.D2 + (int64_t)(cc - a.split) * a.ldd2;
-        const typename vec_of<4>::type a0 = vload<4>(drow + 4 * h), a1 = vload<4>(drow + 8 + 4 * h);
+        // exact form: k = 4 h .. 4 h + 3 and 8 + 4 h ..; split form: k = 8 h .. 8 h + 7
+        const typename vec_of<4>::type a0 = vload<4>(drow + (SPLIT ? 8 : 4) * h),
+                                       a1 = vload<4>(drow + (SPLIT ? 8 * h + 4 : 8 + 4 * h));
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx) { af[jx] = a0[jx]; af[4 + jx] = a1[jx]; }
+        if constexpr (SPLIT) split8(af, a_h, a_m, a_l);
       }
       // gate words of this half's 16 nonzeros: lane li holds words 4 g .. 4 g + 3
       // (g = li >> 4) of the slab's words of nonzero li & 15; a nonzero past the
@@ -544,8 +605,23 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[t][i] = 0.0f;
         if (t < nt) {
+          if constexpr (!SPLIT) {
 #pragma unroll
-          for (int sx = 0; sx < 8; ++sx) T[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sx], bf[t][sx], T[t], 0, 0, 0);
+            for (int sx = 0; sx < 8; ++sx) T[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sx], bf[t][sx], T[t], 0, 0, 0);
+          } else {
+            // smallest partial products first
+            const bf8s wm = __builtin_bit_cast(bf8s, wlow[t * kWave + lane]);
+            const bf8s wl = __builtin_bit_cast(bf8s, wlow[(NT + t) * kWave + lane]);
+            const bf8s wh = __builtin_bit_cast(bf8s, bh[t]);
+            const bf8s xh = __builtin_bit_cast(bf8s, a_h), xm = __builtin_bit_cast(bf8s, a_m),
+                       xl = __builtin_bit_cast(bf8s, a_l);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, T[t], 0, 0, 0);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, T[t], 0, 0, 0);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, T[t], 0, 0, 0);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, T[t], 0, 0, 0);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, T[t], 0, 0, 0);
+            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, T[t], 0, 0, 0);
+          }
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -562,6 +638,10 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
         // that tile's update (bit li of the low word gates lane li, of the high
         // word lane 32 + li): the multiply-add runs under that mask as EXEC.
         uint64_t mask[NT];
+        // the mask the surrounding code runs under (all lanes: the loop bounds here
+        // are wavefront-uniform), read from the hardware and put back after the
+        // gated updates instead of assuming all ones
+        const uint64_t exec_all = __builtin_amdgcn_read_exec();
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int wl = n + 16 * (t >> 2);
@@ -578,22 +658,22 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
               "s_mov_b64 exec, %21\n\tv_fmac_f32 %5, %13, %24\n\t"
               "s_mov_b64 exec, %22\n\tv_fmac_f32 %6, %14, %24\n\t"
               "s_mov_b64 exec, %23\n\tv_fmac_f32 %7, %15, %24\n\t"
-              "s_mov_b64 exec, -1"
+              "s_mov_b64 exec, %25"
               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
                 "+v"(acc[7])
               : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "v"(T[4][n]), "v"(T[5][n]), "v"(T[6][n]),
                 "v"(T[7][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4]), "s"(mask[5]),
-                "s"(mask[6]), "s"(mask[7]), "v"(vs));
+                "s"(mask[6]), "s"(mask[7]), "v"(vs), "s"(exec_all));
         } else {
           asm volatile(
               "s_mov_b64 exec, %8\n\tv_fmac_f32 %0, %4, %12\n\t"
               "s_mov_b64 exec, %9\n\tv_fmac_f32 %1, %5, %12\n\t"
               "s_mov_b64 exec, %10\n\tv_fmac_f32 %2, %6, %12\n\t"
               "s_mov_b64 exec, %11\n\tv_fmac_f32 %3, %7, %12\n\t"
-              "s_mov_b64 exec, -1"
+              "s_mov_b64 exec, %13"
               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
               : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]),
-                "s"(mask[3]), "v"(vs));
+                "s"(mask[3]), "v"(vs), "s"(exec_all));
         }
       }
     }
@@ -1301,14 +1381,17 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
     // width fills them, 128-column slabs otherwise
     const int64_t pairs = ceil_div(k.n_chunks, 2);
     const unsigned gxp = (unsigned)ceil_div(pairs, kWavesPerBlock);
-    if (width % 256 == 0)
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8, true>), dim3(gxp, (unsigned)(width / 256)), dim3(kBlock), 0, st, k);
-    else if (width > 512)
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<8, false>), dim3(gxp, (unsigned)ceil_div(width, 256)), dim3(kBlock), 0, st, k);
-    else if (width % 128 == 0)
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4, true>), dim3(gxp, (unsigned)(width / 128)), dim3(kBlock), 0, st, k);
-    else
-      hipLaunchKernelGGL((spmm_factored_mfma_kernel<4, false>), dim3(gxp, (unsigned)ceil_div(width, 128)), dim3(kBlock), 0, st, k);
+    const bool split = dense_arith_mode() == 0;
+#define GCNX_FACT(NTV, FULLV, GY)                                                                                 \
+  do {                                                                                                            \
+    if (split) hipLaunchKernelGGL((spmm_factored_mfma_kernel<NTV, FULLV, true>), dim3(gxp, (unsigned)(GY)), dim3(kBlock), 0, st, k); \
+    else hipLaunchKernelGGL((spmm_factored_mfma_kernel<NTV, FULLV, false>), dim3(gxp, (unsigned)(GY)), dim3(kBlock), 0, st, k);      \
+  } while (0)
+    if (width % 256 == 0) GCNX_FACT(8, true, width / 256);
+    else if (width > 512) GCNX_FACT(8, false, ceil_div(width, 256));
+    else if (width % 128 == 0) GCNX_FACT(4, true, width / 128);
+    else GCNX_FACT(4, false, ceil_div(width, 128));
+#undef GCNX_FACT
   } else {
     hipLaunchKernelGGL((spmm_factored_kernel<GCNX_FACTORED_U>), dim3(gx, gy), dim3(kBlock), 0, st, k);
   }

@@ -323,6 +323,13 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     return out
 
 
+def dense_arith(mode=None):
+    """Arithmetic of the large dense products on this thread: 0 = exactly split
+    operands on the bf16 matrix pipe (fp32 accuracy, default), 1 = fp32-input MFMA
+    chains only.  Returns the previous mode; ``None`` only reads."""
+    return int(_lib.load().gcnx_dense_arith(-1 if mode is None else int(mode)))
+
+
 def dropout_rows_philox(x, row_ids, keep, seed, offset, out=None):
     """Dropout of gathered rows: row i of ``x`` draws the mask of row
     ``row_ids[i]`` of the [*, W] matrix the mask is defined on (element index

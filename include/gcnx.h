@@ -334,6 +334,18 @@ int gcnx_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                   float *C, int64_t ldc, float alpha, float beta, int fuse_relu,
                   void *ws, size_t ws_bytes, void *stream);
 
+/* Arithmetic of the large dense products (thread-local setting, like the
+ * profiling hook; returns the previous mode; any other argument only reads).
+ * 0 (default): products that fill the matrix pipe run on the bf16 MFMA with every
+ * fp32 operand split exactly into three bf16 pieces and the six partial products
+ * of weight >= 2^-16 accumulated in fp32; the dropped ones are below 2^-23 of each
+ * product, the size of one fp32 rounding, so results carry fp32 accuracy (same
+ * 1e-5 bar against the fp64 yardstick as every other kernel) but are not the bits
+ * of an fp32 multiply-add chain.  1: fp32-input MFMA chains (v_mfma_f32_32x32x2_f32)
+ * only -- exact fp32 arithmetic, at the fp32 vector rate.  Small, skinny and
+ * K <= 32 products always use exact fp32 arithmetic. */
+int gcnx_dense_arith(int mode);
+
 /* The same product with dropout applied to A while its tiles are staged, so
  * dropout(A) is never written: replaces tf.nn.dropout(x) followed by
  * tf.matmul(x', W) (gcn/layers.py:210,215) and, with trans_a, the weight

@@ -168,9 +168,21 @@ def test_spmm_properties_at_scale(env, scale):
     bits = env["ops"].pack_sign_bits(b)
     stored = env["ops"].gemm(d, w2, trans_b=True, gate_bits=bits, gate_scale=2.0, out=b)   # b is free now
     want = env["ops"].spmm(a, stored, out=out)
-    got = env["ops"].spmm_factored(a, d, w2, bits, gate_scale=2.0, trans_w=True)
+    before = env["ops"].dense_arith(1)            # fp32 chains: the bits of the two-kernel path
+    try:
+        got = env["ops"].spmm_factored(a, d, w2, bits, gate_scale=2.0, trans_w=True)
+    finally:
+        env["ops"].dense_arith(before)
     assert torch.equal(got, want)
-    del got, want, stored, d, bits
+    # split operands on the bf16 matrix pipe (the default): fp32 rounding apart,
+    # measured against the size of the summed terms  |A| (gate . 2 |d| |w2|^T)
+    got = env["ops"].spmm_factored(a, d, w2, bits, gate_scale=2.0, trans_w=True)
+    err = (got - want).abs_()
+    del got, want
+    env["ops"].gemm(d.abs(), w2.abs(), trans_b=True, gate_bits=bits, gate_scale=2.0, out=stored)
+    mag = env["ops"].spmm(env["sparse"].Csr(a.n_rows, a.n_cols, a.row_ptr, a.col_idx, a.val.abs()), stored, out=out)
+    assert bool((err <= 2e-6 * mag + 1e-30).all()), float((err / (mag + 1e-30)).max())
+    del err, stored, d, bits, mag
     # transpose of a symmetric matrix reproduces it bit for bit
     t = a.transpose()
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)

@@ -749,14 +749,24 @@ def test_degenerate_sizes_are_no_ops(env):
     torch.cuda.synchronize()
 
 
+@pytest.fixture(params=["split_bf16", "f32_chain"])
+def dense_arith(request, env):
+    """Both arithmetic modes of the large dense products: exactly split operands
+    on the bf16 matrix pipe (default) and fp32-input MFMA chains."""
+    before = env["ops"].dense_arith(0 if request.param == "split_bf16" else 1)
+    yield request.param
+    env["ops"].dense_arith(before)
+
+
 @pytest.mark.parametrize("n,nnz,width,halo", [(3000, 40000, 256, 0), (5000, 90000, 128, 700), (900, 9000, 64, 0),
                                                (4000, 200000, 512, 1500), (1500, 30000, 640, 0),
                                                # fewer nonzeros than one round / one chunk; an odd number of chunks
                                                (40, 30, 256, 0), (300, 9, 256, 5), (2000, 64 * 3 + 1, 256, 0)])
-def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
+def test_spmm_factored_equals_two_kernel_path(env, dense_arith, n, nnz, width, halo):
     """A @ gate(D W^T) with the operand formed per nonzero against the stored
-    intermediate (bit-gated product, then SpMM): same bits; and against the
-    fp64 yardstick.  Hub rows, empty rows, a halo part of the operand."""
+    intermediate (bit-gated product, then SpMM): same bits with fp32 chains, fp32
+    rounding apart with split operands; and against the fp64 yardstick in both.
+    Hub rows, empty rows, a halo part of the operand."""
     torch, ops, dev = env["torch"], env["ops"], env["dev"]
     from gcn_amd.sparse import Csr
     rng = np.random.RandomState(n + width)
@@ -775,7 +785,7 @@ def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
                                 d2=d[n:].contiguous(), gate_bits2=bits[n:].contiguous())
     else:
         got = ops.spmm_factored(a, d, w, bits, gate_scale=2.0, trans_w=True)
-    if width > 128 and n_cols >= 1024:
+    if width > 128 and n_cols >= 1024 and dense_arith == "f32_chain":
         assert torch.equal(got, want)      # both walk a row's nonzeros in order, lane-private sums
     else:
         # at narrow widths the plain SpMM splits a row's nonzeros over lane groups, and
@@ -798,11 +808,11 @@ def test_spmm_factored_equals_two_kernel_path(env, n, nnz, width, halo):
     assert_close_to_f64(got.cpu().numpy(), m @ g64, abs(m) @ gmag, what="factored spmm")
 
 
-def test_spmm_factored_paths_and_general_scale(env):
+def test_spmm_factored_paths_and_general_scale(env, dense_arith):
     """Rows of D with a pitch that rules out 16-byte loads take the vector-ALU
-    form of the kernel; a gate scale that is not a power of two multiplies the
-    matrix value instead of the element (one rounding apart from the two-kernel
-    path, inside the fp32 bar)."""
+    form of the kernel (always fp32 chains); a gate scale that is not a power of
+    two multiplies the matrix value instead of the element (one rounding apart
+    from the two-kernel path, inside the fp32 bar)."""
     torch, ops, dev = env["torch"], env["ops"], env["dev"]
     from gcn_amd.sparse import Csr
     rng = np.random.RandomState(77)
@@ -816,7 +826,12 @@ def test_spmm_factored_paths_and_general_scale(env):
     bits = ops.pack_sign_bits(torch.from_numpy(rng.standard_normal((n, width)).astype(np.float32)).to(dev))
     fast = ops.spmm_factored(a, d, w, bits, gate_scale=2.0, trans_w=True)
     slow = ops.spmm_factored(a, d_odd, w, bits, gate_scale=2.0, trans_w=True)
-    assert torch.equal(fast, slow)
+    if dense_arith == "f32_chain":
+        assert torch.equal(fast, slow)
+    else:
+        mag2 = ops.spmm(Csr(a.n_rows, a.n_cols, a.row_ptr, a.col_idx, a.val.abs()),
+                        ops.gemm(d.abs(), w.abs(), trans_b=True, gate_bits=bits, gate_scale=2.0))
+        assert bool(((fast - slow).abs() <= 1e-6 * mag2 + 1e-30).all())
     for scale in (1.0 / 0.9, 3.0):
         want = ops.spmm(a, ops.gemm(d, w, trans_b=True, gate_bits=bits, gate_scale=scale))
         mag = ops.spmm(Csr(a.n_rows, a.n_cols, a.row_ptr, a.col_idx, a.val.abs()),
@@ -849,3 +864,47 @@ def test_l2_loss_kernel(env, n):
     assert float(base.item()) == 1.25
     again = env["ops"].l2_loss(wt, 5e-4)
     assert np.array_equal(again.cpu().numpy().view(np.uint32), got.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,M,N,K", [("nn", 4096, 256, 256), ("nn", 1000, 512, 64), ("nt", 2048, 256, 128),
+                                        ("tn", 256, 256, 40000), ("tn", 128, 512, 8192 + 16)])
+def test_split_bf16_products_carry_fp32_accuracy(env, kind, M, N, K):
+    """The large products on the bf16 matrix pipe with exactly split operands
+    (gcnx_dense_arith 0) against the fp64 yardstick, next to the fp32-input MFMA
+    chains (mode 1) on the same inputs: both inside the 1e-5 bar, and the split
+    form's worst error within 4x of the chain's (measured: about 1-2x; it drops
+    partial products below 2^-23 of each product and adds six partial sums per
+    16 values of k instead of one chain).  Includes the fused input dropout, whose
+    mask must be identical in both forms, and values spread over 12 binades."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    rng = np.random.RandomState(M + N + K)
+    ta, tb = kind == "tn", kind == "nt"
+    a = (rng.standard_normal((K, M) if ta else (M, K)) * np.exp2(rng.randint(-6, 6, (K, M) if ta else (M, K)))).astype(np.float32)
+    b = (rng.standard_normal((N, K) if tb else (K, N)) * 0.3).astype(np.float32)
+    at, bt = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    ref = env["oracle"].gemm_f64(a, b, ta, tb)
+    mag = env["oracle"].gemm_f64(np.abs(a), np.abs(b), ta, tb)
+    worst = {}
+    outs = {}
+    for mode in (0, 1):
+        before = ops.dense_arith(mode)
+        try:
+            got = ops.gemm(at, bt, trans_a=ta, trans_b=tb).cpu().numpy()
+            dropped = ops.gemm(at, bt, trans_a=ta, trans_b=tb, a_dropout=(0.5, 99, 4 * 1234)).cpu().numpy() \
+                if kind != "nt" else None
+        finally:
+            ops.dense_arith(before)
+        assert_close_to_f64(got, ref, mag, what="%s mode %d" % (kind, mode))
+        worst[mode] = float((np.abs(got - ref) / np.maximum(mag, 1e-30)).max())
+        outs[mode] = dropped
+    assert worst[0] <= 4.0 * worst[1] + 1e-7, worst
+    if kind != "nt":
+        # same Philox mask in both forms: compare against the oracle's mask applied on the host
+        mask = env["oracle"].bernoulli_mask(a.size, 0.5, 99, 4 * 1234).reshape(a.shape)
+        ad = np.where(mask != 0, a * np.float32(2.0), np.float32(0)).astype(np.float32)
+        refd = env["oracle"].gemm_f64(ad, b, ta, tb)
+        magd = env["oracle"].gemm_f64(np.abs(ad), np.abs(b), ta, tb)
+        for mode in (0, 1):
+            assert_close_to_f64(outs[mode], refd, magd, what="%s dropout mode %d" % (kind, mode))
+    print("split-bf16 vs fp32-chain worst error / summed magnitude (%s %dx%dx%d): %.3g vs %.3g" %
+          (kind, M, N, K, worst[0], worst[1]))

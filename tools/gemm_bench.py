@@ -18,8 +18,10 @@ def main():
     ap.add_argument("--classes", type=int, default=16)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="", help="substring of the case name to run")
+    ap.add_argument("--arith", type=int, default=0, help="0: split bf16 operands on the matrix pipe; 1: fp32 MFMA chains")
     args = ap.parse_args()
     from gcn_amd import ops
+    ops.dense_arith(args.arith)
     dev = torch.device("cuda:0")
     n, h, c = args.rows, args.hidden, args.classes
     x = torch.rand((n, h), device=dev) - 0.5
