@@ -31,6 +31,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12  # bytes/s, MI355X HBM3E (spec)
 MFMA_F32_PEAK = 157.3e12  # flop/s, dense fp32 matrix rate of MI355X (256 CUs x 256 flop/clk x 2.4 GHz)
+MFMA_BF16_PEAK = 2.5e15   # flop/s, dense bf16 matrix rate
+# The large products run on the bf16 matrix pipe with every fp32 operand split
+# exactly into three bf16 pieces: six bf16 partial products per fp32 product, so
+# the ceiling of that formulation in fp32-product flop/s is the bf16 peak / 6.
+SPLIT_PARTIAL_PRODUCTS = 6
 
 
 def algorithmic_bytes(nnz, n_rows, width):
@@ -109,6 +114,9 @@ def main():
                     help="first layer as A_hat (X' W1) like the reference (default) or as (A_hat X') W1")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) or gloo (rehearsal: several "
                     "ranks sharing one GPU)")
+    ap.add_argument("--dense-arith", default="split_bf16", choices=["split_bf16", "f32"],
+                    help="large dense products and the factored SpMM's row-forming: exactly split fp32 operands on "
+                         "the bf16 matrix pipe (fp32 accuracy; default) or fp32-input MFMA chains")
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="several GPUs over RCCL: per-step halo exchange / all-reduce through the C ABI "
                          "(gcnx_halo_allgather_f32, default) or through torch.distributed")
@@ -119,6 +127,7 @@ def main():
     import torch.distributed as dist
     from gcn_amd import engine, ops, rmat
 
+    ops.dense_arith(0 if args.dense_arith == "split_bf16" else 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,7 +314,7 @@ def main():
                 "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
                              if comm is not None else "torch.distributed " + args.backend),
-                "order": args.order,
+                "order": args.order, "dense_arith": args.dense_arith,
                 "spmm_per_step": ("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
                                   if args.order == "reference" else
                                   "1 x width %d + 2 x width %d" % (args.features, args.classes)),
@@ -345,14 +354,24 @@ def main():
             }
         if gemm_ev:
             flops = 2.0 * n_loc * args.features * args.hidden
+            split = ops.dense_arith() == 0
+            dense_peak = MFMA_BF16_PEAK / SPLIT_PARTIAL_PRODUCTS if split else MFMA_F32_PEAK
             per = {}
             for s_, e_, kind in gemm_ev:
                 per.setdefault(kind, []).append(s_.elapsed_time(e_) * 1e-3)
             result["roofline_dense"] = {
-                kind: {"bound": "mfma", "kernel": ("gemm_mfma_kernel<256> (dropout(X) W1)" if kind == "nn" else
-                                                   "gemm_mfma_tn_kernel<256> (dropout(X)^T dP1)"),
-                       "achieved": flops / (sum(v) / len(v)) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
-                       "unit": "TFLOP/s", "frac": flops / (sum(v) / len(v)) / MFMA_F32_PEAK,
+                kind: {"bound": "mfma",
+                       "kernel": (("gemm_split_nn_kernel" if split else "gemm_mfma_kernel<256>") + " (dropout(X) W1)"
+                                  if kind == "nn" else
+                                  ("gemm_split_tn_kernel" if split else "gemm_mfma_tn_kernel<256>") +
+                                  " (dropout(X)^T dP1)"),
+                       "arith": ("fp32 operands split exactly into 3 bf16 pieces, 6 partial products per product on "
+                                 "v_mfma_f32_32x32x16_bf16, fp32 accumulate (fp32 accuracy)" if split else
+                                 "v_mfma_f32_32x32x2_f32 chains (exact fp32)"),
+                       "achieved": flops / (sum(v) / len(v)) / 1e12, "peak": dense_peak / 1e12,
+                       "peak_is": ("dense bf16 MFMA peak / 6 partial products" if split else "dense fp32 MFMA peak"),
+                       "fp32_mfma_peak": MFMA_F32_PEAK / 1e12,
+                       "unit": "TFLOP/s (fp32-product flops)", "frac": flops / (sum(v) / len(v)) / dense_peak,
                        "flops_per_launch": flops, "avg_launch_ms": sum(v) / len(v) * 1e3, "launches_timed": len(v)}
                 for kind, v in per.items()}
         if args.cpu_rows and world == 1:

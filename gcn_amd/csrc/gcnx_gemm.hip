@@ -13,6 +13,7 @@
 // in split order, so the sum is reproducible.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gcnx_common.h"
 #include "gcnx_philox.h"
@@ -456,13 +457,13 @@ __global__ __launch_bounds__(kBlock, BN > 128 ? 2 : 3) void gemm_mfma_kernel(con
 // cycles replace eight f32 MFMAs of 64 cycles per 16 values of k, and they
 // co-execute with the vector instructions (Philox, splitting, addressing).
 //
-// Block tile 128 x 256, wavefronts 2 x 2 each 64 x 128 (8 accumulator tiles), K
-// step 16 = one MFMA.  LDS holds the three pieces of the A tile [m][16 k] and of
-// the B tile [n][16 k] as bf16 rows of 32 bytes on a 48-byte pitch (16-byte
-// fragment reads of 16 consecutive rows then fall on 16 different bank groups).
-// A is split while it is staged (after its fused dropout); B -- the weights -- is
-// split once by split_b_kernel into the workspace, laid out so that the B tile of
-// a K step is one contiguous block: Bsp[k / 16][piece][n][k % 16].
+// Block tile 128 x 256, K step 16 = one MFMA; the B tile [n][16 k] lies in LDS as
+// bf16 rows of 32 bytes, three pieces, with an XOR swizzle of the two 16-byte
+// halves of a row (16-byte fragment reads of 16 consecutive rows then fall on 16
+// different bank groups).  B -- the weights -- is split once by split_b_kernel
+// into the workspace, laid out so that the B tile of a K step is one contiguous
+// block: Bsp[k / 16][piece][n][k % 16].  A is split by the wavefront that
+// multiplies it, after its fused dropout (see gemm_split_nn_kernel).
 // ---------------------------------------------------------------------------
 typedef __bf16 __attribute__((ext_vector_type(8))) bf8v;
 typedef int __attribute__((ext_vector_type(4))) i4v;
@@ -479,8 +480,6 @@ __device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsign
 __device__ __forceinline__ unsigned pack_upper(unsigned lo, unsigned hi) {
   return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
-
-constexpr int kSplitPitch = 48;   // bytes between the 32-byte rows of a split tile in LDS
 
 __global__ __launch_bounds__(kBlock) void split_b_kernel(const float *__restrict__ B, int64_t ldb, int trans_b,
                                                          int64_t K, int64_t N, unsigned short *__restrict__ out) {
@@ -499,99 +498,179 @@ __global__ __launch_bounds__(kBlock) void split_b_kernel(const float *__restrict
   out[base + 2 * N * 16] = (unsigned short)(l >> 16);
 }
 
+// The K loop keeps the matrix pipe fed from one wavefront's own instruction
+// stream: while the 48 MFMAs of K step s run, the same wavefront turns the raw
+// fp32 rows of step s + 1 into bf16 fragments (dropout, splitting: vector
+// instructions, which co-execute with bf16 MFMAs).  Wavefront w owns rows
+// 32 w .. 32 w + 31 of the tile and all 256 columns, so the A fragments of a
+// wavefront are nobody else's: they never pass through a shared tile.
+//   * The raw rows of A travel by LDS-DMA (global_load_lds_dwordx4: no
+//     registers) into a landing ring private to the wavefront (3 slots of 32
+//     rows x 64 bytes) and are read back by the same wavefront in MFMA fragment
+//     order: only the wavefront's own in-order load counter is involved.
+//   * The weight tile of step s + 1 travels by LDS-DMA from the workspace straight
+//     into the second of two B tiles, in its final layout; one barrier per step
+//     publishes it.
+// The DMA instructions are inline assembly, so the compiler inserts no waits of
+// its own for them; the one wait per step is written out, its count derived
+// from the issue order, which is the same in every step and wavefront:
+//   [6 x B(s+1)] [2 x A(s+3)]
+// so that "at most 2 outstanding" before the barrier of step s means B(s) and
+// A(s+1) have landed and only A(s+2) may still be in flight.
+constexpr int kNnBM = 128, kNnBN = 256, kNnKB = 16;
+constexpr int kNnBPiece = kNnBN * 32;                           // bytes of one bf16 piece of the B tile
+constexpr int kNnBTile = 3 * kNnBPiece;
+constexpr int kNnRingSlots = 3, kNnRingSlot = 2048;             // 32 raw rows of one K step
+constexpr int kNnLds = 2 * kNnBTile + 4 * kNnRingSlots * kNnRingSlot;   // 72 KiB: two workgroups per CU
+// s_waitcnt immediates (gfx9 encoding: vmcnt in bits 3:0 and 15:14; expcnt 6:4
+// and lgkmcnt 11:8 left at "no wait")
+constexpr int kWaitVm0 = 0x0F70, kWaitVm2 = 0x0F72;
+
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+  return (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char *)p);
+}
+// 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS [lds_base, lds_base + 1 KiB)
+__device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_base)
+               : "memory");
+}
+__device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// 16-byte unit of (row r, half hf) inside a split tile of 32-byte rows: the XOR puts
+// the 16 rows that a 16-lane group of ds_read_b128 touches on 16 different groups of four banks
+__device__ __forceinline__ int split_unit(int r, int hf) { return 2 * r + (hf ^ ((r >> 3) & 1)); }
+// 16-byte unit of (row r, floats 4 q ..) inside a ring slot of 32 raw rows, for the same reason
+__device__ __forceinline__ int ring_unit(int r, int q) { return 4 * r + (q ^ ((r >> 2) & 3)); }
+
+template <bool DROP>   // the Philox dropout of A is compiled in or out: the K loop stays one basic block
 __global__ __launch_bounds__(kBlock, 2) void gemm_split_nn_kernel(const GemmArgs g,
                                                                   const unsigned short *__restrict__ Bsp) {
-  constexpr int BM = 128, BN = 256, KB = 16, P = kSplitPitch;
-  constexpr int kABytes = 3 * BM * P, kBBytes = 3 * BN * P;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kABytes + kBBytes];
-  unsigned char *const As = smem;
-  unsigned char *const Bs = smem + kABytes;
+  constexpr int KB = kNnKB, kBPiece = kNnBPiece;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kNnLds];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
-  const int wm = w >> 1, wn = w & 1;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t m0 = (int64_t)blockIdx.x * kNnBM;
+  const int64_t n0 = (int64_t)blockIdx.y * kNnBN;
+  const int nk = (int)(g.K / KB);
   f16v acc[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-  // staging registers: the next K step's tiles travel here while this step's MFMAs run
-  f4v ra[2];
-  i4v rb[6];
-  auto load_tiles = [&](int64_t kk) {
+  // A: DMA instruction i of the wavefront fills units 64 i .. 64 i + 63 of a ring
+  // slot; the lane fetches the piece (row, q) that belongs in its unit
+  unsigned a_off[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * kBlock;
-      const int m = e >> 2, q = e & 3;
-      const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;   // rows past the end: never stored
-      ra[i] = *reinterpret_cast<const f4v *>(g.A + gm * g.lda + kk + q * 4);
-    }
-    // B tile of this K step: pieces p = 0..2, rows n0 .. n0+255, 32 bytes each
-    const unsigned short *src = Bsp + ((kk >> 4) * 3 * g.N + n0) * 16;
+  for (int i = 0; i < 2; ++i) {
+    const int r = w * 32 + i * 16 + (lane >> 2);
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+    const int64_t rc = m0 + r < g.M ? r : g.M - 1 - m0;        // rows past the end: never stored
+    a_off[i] = (unsigned)(rc * g.lda * 4 + q * 16);
+  }
+  // the fragment of this lane: row li of the wavefront's 32, floats 8 lk .. 8 lk + 7 of the step's 16
+  const int64_t frow = m0 + w * 32 + li < g.M ? m0 + w * 32 + li : g.M - 1;
+  const int64_t drow = DROP && g.adrop_rows ? (int64_t)g.adrop_rows[frow] : frow;
+  // every load issued so far (the row id) completes here, where the compiler sees it
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  const float *const a_tile = g.A + m0 * g.lda;
+  unsigned char *const ring = smem + 2 * kNnBTile + w * (kNnRingSlots * kNnRingSlot);
+  const unsigned ring_lds = lds_offset(ring);
+  // Steps past the end are issued all the same (clamped to the last step: L2
+  // hits, landing in a slot nobody reads any more), so that every step issues
+  // the same eight instructions and the loop body has no branch.
+  auto issue_a = [&](int step, int slot) {
+    const float *base = a_tile + (int64_t)(step < nk ? step : nk - 1) * KB;
+    const unsigned dst = ring_lds + (unsigned)(slot * kNnRingSlot);
+    dma16(base, a_off[0], dst);
+    dma16(base, a_off[1], dst + 1024);
+  };
+  // weight tile: 24 DMA instructions of 64 units, six per wavefront; instruction
+  // id = (piece, block of 32 columns); the lane picks the half-row that belongs in its unit
+  const unsigned b_off = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
+  const unsigned btile_lds = lds_offset(smem);
+  const unsigned char *const b_src = reinterpret_cast<const unsigned char *>(Bsp) + n0 * 32;
+  auto issue_b = [&](int step) {
+    const unsigned dst = btile_lds + (unsigned)((step & 1) * kNnBTile);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int e = tid + i * kBlock;              // 16-byte piece: (p, n, half)
-      rb[i] = *reinterpret_cast<const i4v *>(src + (int64_t)(e >> 9) * g.N * 16 + (e & 511) * 8);
+    for (int j = 0; j < 6; ++j) {
+      const int id = w * 6 + j, p = id >> 3, jj = id & 7;
+      dma16(b_src + ((int64_t)step * 3 + p) * g.N * 32 + jj * 1024, b_off, dst + (unsigned)(p * kBPiece + jj * 1024));
     }
   };
-  auto store_tiles = [&](int64_t kk) {
+  const unsigned char *const raw_lo = ring + ring_unit(li, 2 * lk) * 16;
+  const unsigned char *const raw_hi = ring + ring_unit(li, 2 * lk + 1) * 16;
+  // raw floats of one step -> dropout -> the three bf16 A fragments of this lane
+  auto prep = [&](i4v (&af)[3], int step, int slot) {
+    f4v v[2];
+    v[0] = *reinterpret_cast<const f4v *>(raw_lo + slot * kNnRingSlot);
+    v[1] = *reinterpret_cast<const f4v *>(raw_hi + slot * kNnRingSlot);
+    const int64_t kk = (int64_t)step * KB + lk * 8;
+    unsigned h[8], md[8], l[8];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * kBlock;
-      const int m = e >> 2, q = e & 3;
-      f4v v = ra[i];
-      if (g.adrop_keep < 1.0f) {
-        const int64_t gm = m0 + m < g.M ? m0 + m : g.M - 1;
-        v = drop4(g, v, g.adrop_rows ? (int64_t)g.adrop_rows[gm] : gm, kk + q * 4);
-      }
-      unsigned h[4], md[4], l[4];
+      if (DROP) v[i] = drop4(g, v[i], drow, kk + i * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) split3(v[j], h[j], md[j], l[j]);
-      unsigned char *d = As + m * P + q * 8;
-      *reinterpret_cast<u2v *>(d) = u2v{pack_upper(h[0], h[1]), pack_upper(h[2], h[3])};
-      *reinterpret_cast<u2v *>(d + BM * P) = u2v{pack_upper(md[0], md[1]), pack_upper(md[2], md[3])};
-      *reinterpret_cast<u2v *>(d + 2 * BM * P) = u2v{pack_upper(l[0], l[1]), pack_upper(l[2], l[3])};
+      for (int j = 0; j < 4; ++j) split3(v[i][j], h[i * 4 + j], md[i * 4 + j], l[i * 4 + j]);
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int e = tid + i * kBlock;
-      const int rest = e & 511;
-      *reinterpret_cast<i4v *>(Bs + (e >> 9) * (BN * P) + (rest >> 1) * P + (rest & 1) * 16) = rb[i];
-    }
+    af[0] = i4v{(int)pack_upper(h[0], h[1]), (int)pack_upper(h[2], h[3]), (int)pack_upper(h[4], h[5]),
+                (int)pack_upper(h[6], h[7])};
+    af[1] = i4v{(int)pack_upper(md[0], md[1]), (int)pack_upper(md[2], md[3]), (int)pack_upper(md[4], md[5]),
+                (int)pack_upper(md[6], md[7])};
+    af[2] = i4v{(int)pack_upper(l[0], l[1]), (int)pack_upper(l[2], l[3]), (int)pack_upper(l[4], l[5]),
+                (int)pack_upper(l[6], l[7])};
   };
-  const unsigned char *const a_frag = As + ((wm * 2) * 32 + li) * P + lk * 16;
-  const unsigned char *const b_frag = Bs + ((wn * 4) * 32 + li) * P + lk * 16;
-  load_tiles(0);
-  for (int64_t kk = 0; kk < g.K; kk += KB) {
-    store_tiles(kk);
-    __syncthreads();
-    if (kk + KB < g.K) load_tiles(kk + KB);
-    i4v af[2][3];
+
+  // prologue: A(0), A(1), B(0), A(2); all but A(2) have landed at "2 outstanding"
+  issue_a(0, 0);
+  issue_a(1, 1);
+  issue_b(0);
+  issue_a(2, 2);
+  __builtin_amdgcn_s_waitcnt(kWaitVm2);
+  i4v af[3];
+  prep(af, 0, 0);
+  const int b_frag = split_unit(li, lk) * 16;
+  int slot = 0;                           // ring slot of the raw rows of `step`
+  auto one_step = [&](int step, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;    // another step follows
+    // B(step) and A(step + 1) have landed once only A(step + 2) (2 instructions) may remain
+    __builtin_amdgcn_s_waitcnt(kWaitVm2);
+    block_barrier_lds();                  // B tile of this step visible; the other B tile is free
+    const int next = slot + 1 == kNnRingSlots ? 0 : slot + 1;
+    i4v afn[3];
+    if (MORE) {
+      issue_b(step + 1);
+      issue_a(step + 3, slot);            // this slot's rows were consumed a step ago
+      prep(afn, step + 1, next);
+    }
+    const int bt = b_frag + (step & 1) * kNnBTile;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int pb = 0; pb < 3; ++pb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[tm][p] = *reinterpret_cast<const i4v *>(a_frag + p * (BM * P) + tm * 32 * P);
+      for (int half = 0; half < 2; ++half) {
+        i4v bf[4];
 #pragma unroll
-    for (int pb = 0; pb < 3; ++pb) {
-      i4v bf[4];
+        for (int tn = 0; tn < 4; ++tn)
+          bf[tn] = *reinterpret_cast<const i4v *>(smem + bt + pb * kBPiece + (half * 4 + tn) * 32 * 32);
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) bf[tn] = *reinterpret_cast<const i4v *>(b_frag + pb * (BN * P) + tn * 32 * P);
-#pragma unroll
-      for (int pa = 0; pa + pb < 3; ++pa)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int pa = 0; pa + pb < 3; ++pa)
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn)
-            acc[tm * 4 + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf8v, af[tm][pa]), __builtin_bit_cast(bf8v, bf[tn]), acc[tm * 4 + tn], 0, 0, 0);
+            acc[half * 4 + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf8v, af[pa]), __builtin_bit_cast(bf8v, bf[tn]), acc[half * 4 + tn], 0, 0, 0);
+      }
+    if (MORE) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = afn[p];
+      slot = next;
     }
-    __syncthreads();
-  }
-  store_acc_tiles<2, 4, BM, BN>(g, acc, reinterpret_cast<float *>(smem), w, wm, wn, lane, m0, n0);
+  };
+  for (int step = 0; step + 1 < nk; ++step) one_step(step, std::true_type{});
+  one_step(nk - 1, std::false_type{});
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);   // the clamped DMAs of the last steps
+  __syncthreads();            // the epilogue may reuse the staging memory
+  store_acc_tiles<1, 8, kNnBM, kNnBN>(g, acc, reinterpret_cast<float *>(smem), w, w, 0, lane, m0, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1557,7 +1636,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     // row tiles ride on grid.x (2^31-1 limit); grid.y and .z stop at 65535
     const int64_t mt = ceil_div(M, MB);
     GCNX_REQUIRE(mt <= 0x7fffffffll && N / 128 <= 65535, GCNX_ERR_UNSUPPORTED, "gemm: shape too large");
-    if (dense_arith_mode() == 0 && nn_split_shape(M, N, K) && K * N / kBlock < 0x7fffffffll) {
+    if (dense_arith_mode() == 0 && nn_split_shape(M, N, K) && K * N / kBlock < 0x7fffffffll && lda < (1 << 22)) {
       // exactly split operands on the bf16 matrix pipe; the weights are split first
       const size_t need = nn_split_ws_bytes(N, K);
       GCNX_REQUIRE(ws && ws_bytes >= need && aligned16(ws), GCNX_ERR_WORKSPACE,
@@ -1566,7 +1645,10 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
       hipLaunchKernelGGL(split_b_kernel, dim3((unsigned)ceil_div(K * N, kBlock)), dim3(kBlock), 0, st, B, ldb, trans_b,
                          K, N, bsp);
       GCNX_CHECK_LAUNCH();
-      hipLaunchKernelGGL(gemm_split_nn_kernel, dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g, bsp);
+      if (g.adrop_keep < 1.0f)
+        hipLaunchKernelGGL(gemm_split_nn_kernel<true>, dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g, bsp);
+      else
+        hipLaunchKernelGGL(gemm_split_nn_kernel<false>, dim3((unsigned)mt, (unsigned)(N / 256)), dim3(kBlock), 0, st, g, bsp);
       GCNX_CHECK_LAUNCH();
       return GCNX_OK;
     }
