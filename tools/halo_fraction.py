@@ -6,6 +6,22 @@ import torch
 from gcn_amd import rmat
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1 and sys.argv[1] == "--balance":
+    # nonzeros of every equal-row shard (the scrambled vertex ids balance them)
+    for scale, parts in ((24, 2), (24, 4), (24, 8), (25, 2), (26, 4), (27, 8)):
+        n = 1 << scale
+        n_loc = n // parts
+        counts = []
+        for p in range(parts):
+            keys, nk = rmat.rmat_keys(scale, 8, 123, dev, p * n_loc, (p + 1) * n_loc)
+            row_ptr, col_idx, val, nnz = rmat.csr_from_keys(keys, nk, p * n_loc, (p + 1) * n_loc, n)
+            counts.append(int(nnz))
+            del keys, row_ptr, col_idx, val
+            torch.cuda.empty_cache()
+        mean = sum(counts) / float(parts)
+        print("scale %d, %d equal-row shards: nnz min %d max %d mean %.0f -> max/mean %.4f, min/mean %.4f"
+              % (scale, parts, min(counts), max(counts), mean, max(counts) / mean, min(counts) / mean), flush=True)
+    sys.exit(0)
 for scale, parts in ((24, 8), (25, 2), (26, 4), (27, 8)):
     n = 1 << scale
     n_loc = n // parts
