@@ -510,7 +510,8 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
     nk = left < (int64_t)chunk ? (int)left : chunk;
   }
   const int nk_other = __shfl_xor(nk, HW, kWave);
-  const int nk_max = nk > nk_other ? nk : nk_other;
+  // the same in every lane; held as a scalar so that the round loops are scalar loops
+  const int nk_max = __builtin_amdgcn_readfirstlane(nk > nk_other ? nk : nk_other);
 
   int64_t r = live ? (int64_t)a.chunk_row[ch * a.chunk_mul] : a.n_rows;
   int64_t rbase = r;
@@ -556,75 +557,42 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
   // MFMA row i = li of the A operand is nonzero an of half ah
   const int ah = (li >> 2) & 1, an = (li & 3) + 4 * (li >> 3);
 
-  for (int kb = 0; kb < nk_max; kb += HW) {
-    int cols = 0;
-    float vals = 0.0f;
-    if (kb + li < nk) {
-      cols = a.col_idx[n0 + kb + li];
-      // the gate scale rides on the matrix value (one multiplication per nonzero
-      // instead of one per element)
-      vals = a.val[n0 + kb + li] * a.fscale;
+  // T = D_rows * W for the 32 nonzeros of a round, from the A fragments (exact
+  // form: af, split form: a_h / a_m / a_l)
+  auto form_rows = [&](f16acc (&T)[NT], const float (&af)[8], const i4s &a_h, const i4s &a_m, const i4s &a_l) {
+    // the wavefront that is on the matrix pipe goes first: resident wavefronts
+    // would otherwise share the pipe evenly, stay in step and never overlap
+    // one's matrix phase with the other's vector phase
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) T[t][i] = 0.0f;
+      if (t < nt) {
+        if constexpr (!SPLIT) {
+#pragma unroll
+          for (int sx = 0; sx < 8; ++sx) T[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sx], bf[t][sx], T[t], 0, 0, 0);
+        } else {
+          // smallest partial products first
+          const bf8s wm = __builtin_bit_cast(bf8s, wlow[t * kWave + lane]);
+          const bf8s wl = __builtin_bit_cast(bf8s, wlow[(NT + t) * kWave + lane]);
+          const bf8s wh = __builtin_bit_cast(bf8s, bh[t]);
+          const bf8s xh = __builtin_bit_cast(bf8s, a_h), xm = __builtin_bit_cast(bf8s, a_m),
+                     xl = __builtin_bit_cast(bf8s, a_l);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, T[t], 0, 0, 0);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, T[t], 0, 0, 0);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, T[t], 0, 0, 0);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, T[t], 0, 0, 0);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, T[t], 0, 0, 0);
+          T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, T[t], 0, 0, 0);
+        }
+      }
     }
-#pragma unroll 1
-    for (int sb = 0; sb < 2; ++sb) {
-      const int k0 = kb + 16 * sb;
-      if (k0 >= nk_max) break;
-      // A fragments: D row of nonzero (ah, an) of this round, k = 4 h .. and 8 + 4 h ..
-      float af[8];
-      i4s a_h, a_m, a_l;
-      {
-        const int cc = __shfl(cols, ah * HW + 16 * sb + an, kWave);
-        const float *drow = cc < a.split ? a.D + (int64_t)cc * a.ldd : a.D2 + (int64_t)(cc - a.split) * a.ldd2;
-        // exact form: k = 4 h .. 4 h + 3 and 8 + 4 h ..; split form: k = 8 h .. 8 h + 7
-        const typename vec_of<4>::type a0 = vload<4>(drow + (SPLIT ? 8 : 4) * h),
-                                       a1 = vload<4>(drow + (SPLIT ? 8 * h + 4 : 8 + 4 * h));
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) { af[jx] = a0[jx]; af[4 + jx] = a1[jx]; }
-        if constexpr (SPLIT) split8(af, a_h, a_m, a_l);
-      }
-      // gate words of this half's 16 nonzeros: lane li holds words 4 g .. 4 g + 3
-      // (g = li >> 4) of the slab's words of nonzero li & 15; a nonzero past the
-      // end of the chunk gets zero words, i.e. contributes an exact zero
-      u4v wq = u4v(0u);
-      {
-        const int cw = __shfl(cols, h * HW + 16 * sb + (li & 15), kWave);
-        const int g = li >> 4;
-        if (4 * g < nt && k0 + (li & 15) < nk) {
-          const uint32_t *grow = cw < a.split ? a.gbits + (int64_t)cw * a.ldgb
-                                              : a.gbits2 + (int64_t)(cw - a.split) * a.ldgb2;
-          wq = *reinterpret_cast<const u4v *>(grow + (cbase >> 5) + 4 * g);
-        }
-      }
-      f16acc T[NT];
-      // the wavefront that is on the matrix pipe goes first: resident wavefronts
-      // would otherwise share the pipe evenly, stay in step and never overlap
-      // one's matrix phase with the other's vector phase
-      __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T[t][i] = 0.0f;
-        if (t < nt) {
-          if constexpr (!SPLIT) {
-#pragma unroll
-            for (int sx = 0; sx < 8; ++sx) T[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sx], bf[t][sx], T[t], 0, 0, 0);
-          } else {
-            // smallest partial products first
-            const bf8s wm = __builtin_bit_cast(bf8s, wlow[t * kWave + lane]);
-            const bf8s wl = __builtin_bit_cast(bf8s, wlow[(NT + t) * kWave + lane]);
-            const bf8s wh = __builtin_bit_cast(bf8s, bh[t]);
-            const bf8s xh = __builtin_bit_cast(bf8s, a_h), xm = __builtin_bit_cast(bf8s, a_m),
-                       xl = __builtin_bit_cast(bf8s, a_l);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, T[t], 0, 0, 0);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, T[t], 0, 0, 0);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, T[t], 0, 0, 0);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, T[t], 0, 0, 0);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, T[t], 0, 0, 0);
-            T[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, T[t], 0, 0, 0);
-          }
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // each half walks the 16 nonzeros k0 .. k0 + 15 of its chunk: gate, scale by the
+  // matrix value, add to the open row, close rows at their ends
+  auto walk = [&](const f16acc (&T)[NT], const u4v &wq, float vals, int k0, int sb) {
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
         const int k = k0 + n;
@@ -633,7 +601,10 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
         // the chunk end, which the loop after the rounds would close anyway.)
         while (k == re) close_row();
         const int src = 16 * sb + n;
-        const float vs = __shfl(vals, h * HW + src, kWave);   // the half's own nonzero (LDS crossbar, no vector-ALU slot)
+        // exact form: the half's own matrix value (LDS crossbar, no vector-ALU slot);
+        // split form: the value already multiplies the D row, the update is an addition
+        float vs = 1.0f;
+        if constexpr (!SPLIT) vs = __shfl(vals, h * HW + src, kWave);
         // The two halves' gate words of a tile, side by side, ARE the lane mask of
         // that tile's update (bit li of the low word gates lane li, of the high
         // word lane 32 + li): the multiply-add runs under that mask as EXEC.
@@ -648,7 +619,33 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
           const uint32_t m_lo = (uint32_t)rl_i((int)wq[t & 3], wl), m_hi = (uint32_t)rl_i((int)wq[t & 3], HW + wl);
           mask[t] = ((uint64_t)m_hi << 32) | m_lo;
         }
-        if constexpr (NT == 8) {
+        if constexpr (SPLIT && NT == 8) {
+          asm volatile(
+              "s_mov_b64 exec, %16\n\tv_add_f32 %0, %0, %8\n\t"
+              "s_mov_b64 exec, %17\n\tv_add_f32 %1, %1, %9\n\t"
+              "s_mov_b64 exec, %18\n\tv_add_f32 %2, %2, %10\n\t"
+              "s_mov_b64 exec, %19\n\tv_add_f32 %3, %3, %11\n\t"
+              "s_mov_b64 exec, %20\n\tv_add_f32 %4, %4, %12\n\t"
+              "s_mov_b64 exec, %21\n\tv_add_f32 %5, %5, %13\n\t"
+              "s_mov_b64 exec, %22\n\tv_add_f32 %6, %6, %14\n\t"
+              "s_mov_b64 exec, %23\n\tv_add_f32 %7, %7, %15\n\t"
+              "s_mov_b64 exec, %24"
+              : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                "+v"(acc[7])
+              : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "v"(T[4][n]), "v"(T[5][n]), "v"(T[6][n]),
+                "v"(T[7][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]), "s"(mask[3]), "s"(mask[4]), "s"(mask[5]),
+                "s"(mask[6]), "s"(mask[7]), "s"(exec_all));
+        } else if constexpr (SPLIT) {
+          asm volatile(
+              "s_mov_b64 exec, %8\n\tv_add_f32 %0, %0, %4\n\t"
+              "s_mov_b64 exec, %9\n\tv_add_f32 %1, %1, %5\n\t"
+              "s_mov_b64 exec, %10\n\tv_add_f32 %2, %2, %6\n\t"
+              "s_mov_b64 exec, %11\n\tv_add_f32 %3, %3, %7\n\t"
+              "s_mov_b64 exec, %12"
+              : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+              : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]),
+                "s"(mask[3]), "s"(exec_all));
+        } else if constexpr (NT == 8) {
           asm volatile(
               "s_mov_b64 exec, %16\n\tv_fmac_f32 %0, %8, %24\n\t"
               "s_mov_b64 exec, %17\n\tv_fmac_f32 %1, %9, %24\n\t"
@@ -675,6 +672,135 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
               : "v"(T[0][n]), "v"(T[1][n]), "v"(T[2][n]), "v"(T[3][n]), "s"(mask[0]), "s"(mask[1]), "s"(mask[2]),
                 "s"(mask[3]), "v"(vs), "s"(exec_all));
         }
+      }
+  };
+
+  if constexpr (SPLIT) {
+    // The gathers of round j + 1 (per nonzero the 64-byte row of D and the slab's
+    // gate words) are issued at the top of round j and land, by LDS-DMA
+    // (global_load_lds_dwordx4: no registers), in one of two wavefront-private
+    // landing slots; a lane reads back exactly the bytes it asked for, so no
+    // barrier and no layout is involved -- LDS is a register-free prefetch buffer.
+    // The DMA instructions are inline assembly (the compiler inserts no waits of
+    // its own for them); the wait for round j's data is written out: the three
+    // instructions of round j + 1 are the newest in the wavefront's in-order
+    // queue, so "at most 3 outstanding" means round j has landed.  col_idx / val
+    // travel one block of 32 nonzeros ahead in registers.
+    __shared__ __attribute__((aligned(16))) i4s land[kWavesPerBlock][2][3 * kWave];
+    i4s *const my_land = &land[wid][0][0];
+    const unsigned land_lds = (unsigned)(size_t)((__attribute__((address_space(3))) i4s *)my_land);
+    const int gq = 4 * (li >> 4) < nt ? (li >> 4) : 0;   // gate words 4 gq .. 4 gq + 3 of the slab (clamped: masked below)
+    auto load_block = [&](int kb, int &cols, float &vals) {
+      cols = 0;
+      vals = 0.0f;
+      if (kb + li < nk) {
+        cols = a.col_idx[n0 + kb + li];
+        vals = a.val[n0 + kb + li] * a.fscale;   // the gate scale rides on the matrix value
+      }
+    };
+    // operand bases and pitches as opaque scalars (otherwise the per-lane choice
+    // between the two operands becomes a choice between two kernel-argument
+    // addresses followed by dependent loads, inside the loop)
+    const float *d1 = a.D, *d2 = a.D2;
+    const uint32_t *g1 = a.gbits, *g2 = a.gbits2;
+    int64_t ld1 = a.ldd, ld2 = a.ldd2, lg1 = a.ldgb, lg2 = a.ldgb2;
+    int split = a.split;
+    asm volatile("" : "+s"(d1), "+s"(d2), "+s"(g1), "+s"(g2));
+    asm volatile("" : "+s"(ld1), "+s"(ld2), "+s"(lg1), "+s"(lg2), "+s"(split));
+    auto issue = [&](int cols, int sb, int slot) {
+      const int cc = __shfl(cols, ah * HW + 16 * sb + an, kWave);
+      const float *r1 = d1 + (int64_t)cc * ld1, *r2 = d2 + (int64_t)(cc - split) * ld2;
+      const float *drow = (cc < split ? r1 : r2) + 8 * h;
+      const int cw = __shfl(cols, h * HW + 16 * sb + (li & 15), kWave);
+      const uint32_t *w1 = g1 + (int64_t)cw * lg1, *w2 = g2 + (int64_t)(cw - split) * lg2;
+      const uint32_t *grow = (cw < split ? w1 : w2) + (cbase >> 5) + 4 * gq;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(land_lds + (unsigned)(slot * 3 * kWave * 16)));
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off"
+                   ::"v"(drow), "v"(drow + 4), "v"(grow), "s"(dst)
+                   : "memory");
+    };
+    int cols, cols_n = 0;
+    float vals, vals_n = 0.0f;
+    load_block(0, cols, vals);
+    issue(cols, 0, 0);
+    int slot = 0;
+    for (int kb = 0; kb < nk_max; kb += HW) {
+      if (kb + HW < nk_max) load_block(kb + HW, cols_n, vals_n);
+#pragma unroll 1
+      for (int sb = 0; sb < 2; ++sb) {
+        const int k0 = kb + 16 * sb;
+        if (k0 >= nk_max) break;
+        if (k0 + 16 < nk_max) {
+          issue(sb == 0 ? cols : cols_n, sb ^ 1, slot ^ 1);
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const i4s *src = my_land + slot * 3 * kWave + lane;
+        const typename vec_of<4>::type a0 = __builtin_bit_cast(typename vec_of<4>::type, src[0]),
+                                       a1 = __builtin_bit_cast(typename vec_of<4>::type, src[kWave]);
+        u4v wq = __builtin_bit_cast(u4v, src[2 * kWave]);
+        // a nonzero past the end of the chunk (and a lane whose words lie outside
+        // the slab) gets zero words, i.e. contributes an exact zero
+        if (!(4 * (li >> 4) < nt && k0 + (li & 15) < nk)) wq = u4v(0u);
+        // the matrix value (times the gate scale) of this lane's nonzero multiplies its
+        // D row here, once per round, so that the walk below only adds
+        const float mv = __shfl(vals, ah * HW + 16 * sb + an, kWave);
+        float af[8];
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) { af[jx] = a0[jx] * mv; af[4 + jx] = a1[jx] * mv; }
+        i4s a_h, a_m, a_l;
+        split8(af, a_h, a_m, a_l);
+        f16acc T[NT];
+        form_rows(T, af, a_h, a_m, a_l);
+        walk(T, wq, vals, k0, sb);
+        slot ^= 1;
+      }
+      cols = cols_n;
+      vals = vals_n;
+    }
+  } else {
+    for (int kb = 0; kb < nk_max; kb += HW) {
+      int cols = 0;
+      float vals = 0.0f;
+      if (kb + li < nk) {
+        cols = a.col_idx[n0 + kb + li];
+        // the gate scale rides on the matrix value (one multiplication per nonzero
+        // instead of one per element)
+        vals = a.val[n0 + kb + li] * a.fscale;
+      }
+#pragma unroll 1
+      for (int sb = 0; sb < 2; ++sb) {
+        const int k0 = kb + 16 * sb;
+        if (k0 >= nk_max) break;
+        // A fragments: D row of nonzero (ah, an) of this round, k = 4 h .. and 8 + 4 h ..
+        float af[8];
+        i4s a_h = {0, 0, 0, 0}, a_m = a_h, a_l = a_h;
+        {
+          const int cc = __shfl(cols, ah * HW + 16 * sb + an, kWave);
+          const float *drow = cc < a.split ? a.D + (int64_t)cc * a.ldd : a.D2 + (int64_t)(cc - a.split) * a.ldd2;
+          const typename vec_of<4>::type a0 = vload<4>(drow + 4 * h), a1 = vload<4>(drow + 8 + 4 * h);
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) { af[jx] = a0[jx]; af[4 + jx] = a1[jx]; }
+        }
+        // gate words of this half's 16 nonzeros: lane li holds words 4 g .. 4 g + 3
+        // (g = li >> 4) of the slab's words of nonzero li & 15; a nonzero past the
+        // end of the chunk gets zero words, i.e. contributes an exact zero
+        u4v wq = u4v(0u);
+        {
+          const int cw = __shfl(cols, h * HW + 16 * sb + (li & 15), kWave);
+          const int g = li >> 4;
+          if (4 * g < nt && k0 + (li & 15) < nk) {
+            const uint32_t *grow = cw < a.split ? a.gbits + (int64_t)cw * a.ldgb
+                                                : a.gbits2 + (int64_t)(cw - a.split) * a.ldgb2;
+            wq = *reinterpret_cast<const u4v *>(grow + (cbase >> 5) + 4 * g);
+          }
+        }
+        f16acc T[NT];
+        form_rows(T, af, a_h, a_m, a_l);
+        walk(T, wq, vals, k0, sb);
       }
     }
   }
@@ -1403,4 +1529,5 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
   if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
   return GCNX_OK;
 }
+
 

@@ -866,7 +866,8 @@ def test_l2_loss_kernel(env, n):
     assert np.array_equal(again.cpu().numpy().view(np.uint32), got.cpu().numpy().view(np.uint32))
 
 
-@pytest.mark.parametrize("kind,M,N,K", [("nn", 4096, 256, 256), ("nn", 1000, 512, 64), ("nt", 2048, 256, 128),
+@pytest.mark.parametrize("kind,M,N,K", [("nn", 4096, 256, 256), ("nn", 1000, 512, 64), ("nn", 513, 256, 80),
+                                        ("nn", 2049, 256, 1040), ("nt", 2048, 256, 128),
                                         ("tn", 256, 256, 40000), ("tn", 128, 512, 8192 + 16)])
 def test_split_bf16_products_carry_fp32_accuracy(env, kind, M, N, K):
     """The large products on the bf16 matrix pipe with exactly split operands
@@ -908,3 +909,30 @@ def test_split_bf16_products_carry_fp32_accuracy(env, kind, M, N, K):
             assert_close_to_f64(outs[mode], refd, magd, what="%s dropout mode %d" % (kind, mode))
     print("split-bf16 vs fp32-chain worst error / summed magnitude (%s %dx%dx%d): %.3g vs %.3g" %
           (kind, M, N, K, worst[0], worst[1]))
+
+
+def test_split_nn_product_on_strided_operands(env):
+    """The split NN kernel streams A by LDS-DMA from (base + per-lane offset)
+    addresses: A as a column slab of a wider matrix (row pitch > K, 16-byte
+    aligned start), C as a column slab of a wider output, the last row tile one
+    row deep, K steps: 5 (fewer than the three DMA slots' worth of look-ahead
+    plus a clamped tail)."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    rng = np.random.RandomState(77)
+    M, N, K = 1025, 256, 80
+    wide = rng.standard_normal((M, K + 48)).astype(np.float32)
+    b = (rng.standard_normal((K, N)) * 0.2).astype(np.float32)
+    wt = torch.from_numpy(wide).to(dev)
+    a_view = wt[:, 16:16 + K]                       # pitch K + 48, offset 64 bytes
+    out_wide = torch.full((M, N + 64), 7.0, device=dev)
+    out_view = out_wide[:, 32:32 + N]
+    before = ops.dense_arith(0)
+    try:
+        ops.gemm(a_view, torch.from_numpy(b).to(dev), out=out_view)
+    finally:
+        ops.dense_arith(before)
+    a = wide[:, 16:16 + K]
+    assert_close_to_f64(out_view.cpu().numpy(), env["oracle"].gemm_f64(a, b, False, False),
+                        env["oracle"].gemm_f64(np.abs(a), np.abs(b), False, False), what="strided split nn")
+    got = out_wide.cpu().numpy()
+    assert (got[:, :32] == 7.0).all() and (got[:, 32 + N:] == 7.0).all()   # nothing outside the slab is written
