@@ -221,10 +221,10 @@ __device__ __forceinline__ void store_tile_relu_dropout(const GemmArgs &g, const
       const uint64_t e0 = g.odrop_offset + (uint64_t)gm * (uint64_t)g.odrop_ld + (uint64_t)(g.odrop_col0 + gn);
       const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, g.odrop_seed);
       f4v o;
-      o.x = ((float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.x, 0.0f) : v.x) * inv : 0.0f;
-      o.y = ((float)(rnd.v[1] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.y, 0.0f) : v.y) * inv : 0.0f;
-      o.z = ((float)(rnd.v[2] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.z, 0.0f) : v.z) * inv : 0.0f;
-      o.w = ((float)(rnd.v[3] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? (g.relu ? fmaxf(v.w, 0.0f) : v.w) * inv : 0.0f;
+      o.x = ((float)(rnd.v[0] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? ((g.relu && v.x < 0.0f) ? 0.0f : v.x) * inv : 0.0f;
+      o.y = ((float)(rnd.v[1] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? ((g.relu && v.y < 0.0f) ? 0.0f : v.y) * inv : 0.0f;
+      o.z = ((float)(rnd.v[2] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? ((g.relu && v.z < 0.0f) ? 0.0f : v.z) * inv : 0.0f;
+      o.w = ((float)(rnd.v[3] >> 8) * (1.0f / 16777216.0f) < g.odrop_keep) ? ((g.relu && v.w < 0.0f) ? 0.0f : v.w) * inv : 0.0f;
       *reinterpret_cast<f4v *>(g.C + gm * g.ldc + gn) = o;
       if (g.osign) {
         // the 8 lanes of a row of this 32-column tile hold one sign word between
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void gemm_small_k_kernel(const GemmArgs g) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float o = g.alpha * acc[i][j] + g.beta * old[i][j];
-          if (g.relu) o = fmaxf(o, 0.0f);
+          if (g.relu && o < 0.0f) o = 0.0f;   // a NaN stays a NaN
           if (g.gate) o = gt[i][j] > 0.0f ? o * g.gate_scale : 0.0f;
           out[j] = o;
         }
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
         for (int rg = 0; rg < 16; ++rg) {
           const int ro = (rg & 3) + 8 * (rg >> 2);
           float o = g.alpha * acc[rg];
-          if (g.relu) o = fmaxf(o, 0.0f);
+          if (g.relu && o < 0.0f) o = 0.0f;   // a NaN stays a NaN
           if constexpr (GATE != 0) o = gt[rg] > 0.0f ? o * g.gate_scale : 0.0f;
           __builtin_nontemporal_store(o, g.C + (r0 + ro) * g.ldc + tc0 + c_off);
         }
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_small_k_mfma_kernel(const Gemm
             float *dst = g.C + row * g.ldc + col;
             float o = g.alpha * acc[rg];
             if (g.beta != 0.0f) o += g.beta * *dst;
-            if (g.relu) o = fmaxf(o, 0.0f);
+            if (g.relu && o < 0.0f) o = 0.0f;   // a NaN stays a NaN
             if constexpr (GATE == 1) o = g.gate[row * g.ldgate + col] > 0.0f ? o * g.gate_scale : 0.0f;
             if constexpr (GATE == 2)
               o = ((g.gate_bits[row * g.ldbits + (col >> 5)] >> (col & 31)) & 1u) ? o * g.gate_scale : 0.0f;
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(kBlock, 1) void gemm_skinny_n_kernel(const GemmArgs
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         float o = g.alpha * acc[rg];
-        if (g.relu) o = fmaxf(o, 0.0f);
+        if (g.relu && o < 0.0f) o = 0.0f;   // a NaN stays a NaN
         my[(4 * lq + rg) * 16 + li] = o;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -39,12 +39,14 @@ __device__ __forceinline__ void vstore(float *p, typename vec_of<VEC>::type v) {
 }
 template <int VEC>
 __device__ __forceinline__ typename vec_of<VEC>::type vmax0(typename vec_of<VEC>::type v) {
+  // compare-and-select, not fmaxf: a NaN sum stays a NaN (as relu does in the
+  // reference's framework), so that a diverged run shows up in the loss
   if constexpr (VEC == 1) {
-    return fmaxf(v, 0.0f);
+    return v < 0.0f ? 0.0f : v;
   } else {
     typename vec_of<VEC>::type o;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = fmaxf(v[i], 0.0f);
+    for (int i = 0; i < VEC; ++i) o[i] = v[i] < 0.0f ? 0.0f : v[i];
     return o;
   }
 }
@@ -1084,7 +1086,7 @@ __global__ void spmm_empty_kernel(const SpmmArgs a) {
   if (i >= a.n_rows * (int64_t)a.width) return;
   float *dst = a.C + (i / a.width) * a.ldc + (i % a.width);
   float out = a.beta != 0.0f ? *dst * a.beta : 0.0f;
-  if (a.relu) out = fmaxf(out, 0.0f);
+  if (a.relu && out < 0.0f) out = 0.0f;   // a NaN stays a NaN
   if (a.drop_keep < 1.0f) {
     const uint64_t e0 = a.drop_offset + (uint64_t)(i / a.width) * (uint64_t)a.drop_ld +
                         (uint64_t)(a.drop_col0 + (i % a.width));

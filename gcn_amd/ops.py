@@ -1,7 +1,14 @@
 """Python entry points of the HIP kernels + their autograd glue.
 
-torch is used for tensor ownership, streams and the autograd tape only; every
-product, reduction and update below runs in ``libgcnhip.so`` through ctypes.
+torch is used for tensor ownership, streams and the autograd tape; every
+product, reduction, loss and update below runs in ``libgcnhip.so`` through
+ctypes.  What the drop-in layer path (``gcn_amd/layers.py``) leaves to torch's
+own element-wise kernels, all of them off the measured path: the concatenation
+of the per-support weights of a Chebyshev layer (``torch.cat``, once per step),
+a layer's optional bias add, a relu that cannot be fused into the product that
+feeds it (``torch.relu``), the ``x.repeat`` of the featureless multi-support
+case and the ``part(k) - b2`` of the opt-in Clenshaw recurrence.  The large-graph
+engine (``gcn_amd/engine.py``) uses none of them.
 All functions raise on CPU tensors -- there is no fallback path.
 """
 import ctypes as C

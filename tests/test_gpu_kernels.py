@@ -936,3 +936,45 @@ def test_split_nn_product_on_strided_operands(env):
                         env["oracle"].gemm_f64(np.abs(a), np.abs(b), False, False), what="strided split nn")
     got = out_wide.cpu().numpy()
     assert (got[:, :32] == 7.0).all() and (got[:, 32 + N:] == 7.0).all()   # nothing outside the slab is written
+
+
+def test_relu_epilogues_propagate_nan(env):
+    """relu in the reference's framework maps NaN to NaN; every fused relu here is
+    a compare-and-select that does the same, in full and edge tiles of the dense
+    kernels (both arithmetic modes, large and small shapes) and in the SpMM
+    epilogues (wide, narrow and small-matrix kernels), so that a diverged run
+    surfaces as a NaN loss instead of being clamped to zero."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in ((1000, 256, 64), (700, 64, 48), (300, 16, 256), (130, 24, 20)):
+        a = torch.randn(M, K, generator=g).to(dev)
+        b = torch.randn(K, N, generator=g).to(dev)
+        rows = [0, M // 2, M - 1]                     # first tile, interior, last (edge) tile
+        for r in rows:
+            a[r, 3] = float("nan")
+        for mode in (0, 1):
+            before = ops.dense_arith(mode)
+            try:
+                out = ops.gemm(a, b, relu=True)
+            finally:
+                ops.dense_arith(before)
+            bad = torch.isnan(out).all(dim=1).cpu().numpy()
+            assert bad[rows].all(), (M, N, K, mode)
+            assert bad.sum() == len(rows)
+            assert (out[~torch.isnan(out)] >= 0).all()
+    # SpMM: a NaN in row c of the dense operand reaches every row that references column c
+    for n, nnz, w in ((3000, 60000, 256), (3000, 60000, 16), (300, 2000, 32)):
+        rng = np.random.RandomState(n + w)
+        r = rng.randint(0, n, nnz).astype(np.int32)
+        c = rng.randint(0, n, nnz).astype(np.int32)
+        v = rng.standard_normal(nnz).astype(np.float32)
+        a = Csr.from_coo(torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(v).to(dev), (n, n),
+                         device=dev)
+        b = torch.randn(n, w, generator=g).to(dev)
+        b[7, :] = float("nan")
+        out = ops.spmm(a, b, relu=True)
+        hit = np.zeros(n, bool)
+        hit[r[c == 7]] = True
+        got = torch.isnan(out).all(dim=1).cpu().numpy()
+        assert np.array_equal(got, hit), (n, nnz, w)
