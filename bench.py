@@ -219,8 +219,25 @@ def main():
         # ncclSend / ncclRecv on its own communicator); torch.distributed only
         # carries the communicator id and the set-up lists
         from gcn_amd.comm import RcclComm
-        comm = RcclComm(group, world, rank, dev)
-        note("C-ABI communicator up")
+        ok, why = 1, ""
+        try:
+            comm = RcclComm(group, world, rank, dev)
+            # self-check before anything is timed: known answers through the same entry points
+            good, why = comm.self_check()
+            ok = 1 if good else 0
+        except Exception as exc:       # RCCL not loadable, communicator not creatable, ...
+            ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
+        if int(agree.item()) == 0:
+            # every rank falls back together: the per-step collectives go through torch.distributed
+            print("[rank %d] C-ABI collectives unavailable (%s); using torch.distributed" % (rank, why or "a peer failed"),
+                  file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm = None
+        else:
+            note("C-ABI communicator up, self-check passed")
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                        row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
                        slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm)

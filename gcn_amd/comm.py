@@ -55,6 +55,26 @@ class RcclComm(object):
             _lib.load().gcnx_comm_destroy(self._comm)
         self._comm = None
 
+    def self_check(self):
+        """An all-reduce and a 2-rows-per-rank exchange with known answers through
+        the same entry points the training step uses (collective: every rank of
+        the communicator calls it).  Returns (ok, reason)."""
+        dev, world, rank = self.device, self.world, self.rank
+        with torch.cuda.device(dev):
+            probe = torch.full((8,), float(rank + 1), device=dev)
+            self.allreduce_sum_(probe)
+            counts = [2] * world
+            send = torch.cat([torch.full((2, 4), float(rank * 1000 + p), device=dev) for p in range(world)])
+            recv = torch.zeros((2 * world, 4), device=dev)
+            self.exchange_rows(recv, send, counts, counts).wait()
+            torch.cuda.synchronize(dev)
+        want = torch.cat([torch.full((2, 4), float(p * 1000 + rank)) for p in range(world)])
+        if float(probe[0]) != world * (world + 1) / 2:
+            return False, "all-reduce returned %r, expected %r" % (float(probe[0]), world * (world + 1) / 2)
+        if not torch.equal(recv.cpu(), want):
+            return False, "row exchange delivered wrong rows"
+        return True, ""
+
     # ------------------------------------------------------------------ plans
     def _plan_struct(self, send_counts, recv_counts, send_idx):
         """ctypes mirror of ``gcnx_halo_exchange`` (cached per count lists /

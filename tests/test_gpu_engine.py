@@ -273,6 +273,8 @@ def _comm_worker(out_path):
     comm.allreduce_sum_(t)
     torch.cuda.synchronize()
     res["allreduce_equal"] = bool(torch.equal(t, keep))
+    # (5) the self-check bench.py runs before it trusts the communicator
+    res["self_check"] = list(comm.self_check())
     comm.close()
     dist.destroy_process_group()
     with open(out_path, "w") as fh:
@@ -298,4 +300,4 @@ def test_cabi_rccl_exchange_single_rank(tmp_path):
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     res = json.load(open(out))
     assert res == {"gathered_equal": True, "words_equal": True, "bad_counts": "ValueError", "bad_plan": -1,
-                   "allreduce_equal": True}, res
+                   "allreduce_equal": True, "self_check": [True, ""]}, res
