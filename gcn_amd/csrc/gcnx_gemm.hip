@@ -827,6 +827,7 @@ __device__ __forceinline__ bf8v tr_frag(const unsigned char *p, int row_pitch) {
   return __builtin_bit_cast(bf8v, v);
 }
 
+template <bool DROP>   // the Philox dropout of A compiled in or out
 __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs g) {
   constexpr int BM = 128, BN = 256, BK = 16;
   constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;           // row pitches in bytes
@@ -867,6 +868,23 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs
       if (whole || kk + k < kend) rb[i] = *reinterpret_cast<const f4v *>(g.B + (kk + k) * g.ldb + n0 + q * 4);
     }
   };
+  // The dropout mask of the A pieces this thread stages at step kk is a function
+  // of indices only: it is drawn (Philox, ~150 vector instructions) in the shadow
+  // of the previous step's MFMAs and kept as 8 bits.
+  unsigned keep_bits = 0;
+  auto draw_keep = [&](int64_t kk) {
+    keep_bits = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * kBlock;
+      const int k = e >> 5, q = e & 31;
+      const uint64_t e0 = g.adrop_offset + (uint64_t)(kk + k) * (uint64_t)g.adrop_ld + (uint64_t)(m0 + q * 4);
+      const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, g.adrop_seed);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        keep_bits |= ((float)(rnd.v[j] >> 8) * (1.0f / 16777216.0f) < g.adrop_keep ? 1u : 0u) << (4 * i + j);
+    }
+  };
   auto put3 = [&](unsigned char *d, int piece_bytes, f4v v) {
     unsigned h[4], md[4], l[4];
 #pragma unroll
@@ -881,7 +899,12 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
       f4v v = ra[i];
-      if (g.adrop_keep < 1.0f) v = drop4(g, v, kk + k, m0 + q * 4);   // rows past kend hold zeros
+      if (DROP) {
+        // keep bits drawn while the previous step's MFMAs ran (draw_keep); rows past kend hold zeros
+        const float inv = 1.0f / g.adrop_keep;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((keep_bits >> (4 * i + j)) & 1u) ? v[j] * inv : 0.0f;
+      }
       put3(As + k * PA + q * 8, kAPiece, v);
     }
 #pragma unroll
@@ -899,10 +922,12 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs
   const int b_tr = ((grp >> 1) * 8 + gq) * PB + ((wn * 4) * 32 + (grp & 1) * 16 + gp * 4) * 2;
   (void)li; (void)lk;
   if (kbeg < kend) load_tiles(kbeg);
+  if (DROP && kbeg < kend) draw_keep(kbeg);
   for (int64_t kk = kbeg; kk < kend; kk += BK) {
     store_tiles(kk);
     __syncthreads();
     if (kk + BK < kend) load_tiles(kk + BK);
+    if (DROP) draw_keep(kk + BK);           // past the last step: drawn and not used (no branch in the MFMA block)
     bf8v af[2][3];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -1684,8 +1709,12 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     }
     if (N % 256 == 0 && dense_arith_mode() == 0) {
       // exactly split operands on the bf16 matrix pipe
-      hipLaunchKernelGGL(gemm_split_tn_kernel, dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
-                         dim3(kBlock), 0, st, g);
+      if (g.adrop_keep < 1.0f)
+        hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
+                           dim3(kBlock), 0, st, g);
+      else
+        hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
+                           dim3(kBlock), 0, st, g);
     } else if (N % 256 == 0) {
       // 128 x 256 tiles: each workgroup reads its slice of A (and regenerates its
       // dropout) once per 256 output columns
