@@ -529,7 +529,9 @@ constexpr int kWaitVm0 = 0x0F70, kWaitVm2 = 0x0F72;
 __device__ __forceinline__ unsigned lds_offset(const void *p) {
   return (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char *)p);
 }
-// 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS [lds_base, lds_base + 1 KiB)
+// 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS [lds_base, lds_base + 1 KiB).
+// M0 (the LDS base of the DMA) is a reserved register: the compiler keeps no value in it across
+// instructions and rewrites it before every use of its own, so the write here needs no clobber entry.
 __device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_base)
                : "memory");
