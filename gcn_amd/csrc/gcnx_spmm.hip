@@ -729,7 +729,6 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
     issue(cols, 0, 0);
     int slot = 0;
     for (int kb = 0; kb < nk_max; kb += HW) {
-      if (kb + HW < nk_max) load_block(kb + HW, cols_n, vals_n);
 #pragma unroll 1
       for (int sb = 0; sb < 2; ++sb) {
         const int k0 = kb + 16 * sb;
@@ -740,6 +739,9 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // the next block's col_idx / val go out behind the wait (they are first
+        // needed a round from now; ahead of it the wait would cover them too)
+        if (sb == 0 && kb + HW < nk_max) load_block(kb + HW, cols_n, vals_n);
         const i4s *src = my_land + slot * 3 * kWave + lane;
         const typename vec_of<4>::type a0 = __builtin_bit_cast(typename vec_of<4>::type, src[0]),
                                        a1 = __builtin_bit_cast(typename vec_of<4>::type, src[kWave]);
