@@ -95,6 +95,7 @@ SIGNATURES = {
     "gcnx_halo_plan_workspace_bytes": (_sz, [_i64]),
     "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
     "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "gcnx_scatter_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_comm_available": (_int, []),
     "gcnx_comm_unique_id": (_int, [_p]),
     "gcnx_comm_create": (_int, [_i32, _i32, _p, C.POINTER(C.c_void_p)]),

@@ -247,6 +247,28 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(int64_t n_idx,
   }
 }
 
+// the inverse placement: dst[idx[j], :] = src[j, :] (distinct idx: no two rows collide)
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(int64_t n_idx,
+                                                             const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ src,
+                                                             int64_t lds, int32_t width,
+                                                             float *__restrict__ dst, int64_t ldd,
+                                                             int vec) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  const int per_row = vec ? width / 4 : width;
+  const int64_t total = n_idx * (int64_t)per_row;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / per_row;
+    const int q = (int)(e % per_row);
+    const int64_t r = idx[j];
+    if (vec)
+      reinterpret_cast<f4 *>(dst + r * ldd)[q] = reinterpret_cast<const f4 *>(src + j * lds)[q];
+    else
+      dst[r * ldd + q] = src[j * lds + q];
+  }
+}
+
 }  // namespace gcnx
 
 using namespace gcnx;
@@ -334,6 +356,25 @@ extern "C" int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const flo
   int64_t blocks = ceil_div(total, kBlock);
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
+                     n_idx, idx, src, lds, width, dst, ldd, vec);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_scatter_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
+                                     int64_t lds, int32_t width, float *dst, int64_t ldd,
+                                     void *stream) {
+  GCNX_REQUIRE(n_idx >= 0 && width >= 0, GCNX_ERR_INVALID_ARG, "scatter_rows: negative size");
+  if (n_idx == 0 || width == 0) return GCNX_OK;
+  GCNX_REQUIRE(idx && src && dst && lds >= width && ldd >= width, GCNX_ERR_INVALID_ARG,
+               "scatter_rows: bad argument");
+  const int vec = (width % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+  const int64_t total = n_idx * (int64_t)(vec ? width / 4 : width);
+  int64_t blocks = ceil_div(total, kBlock);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
                      n_idx, idx, src, lds, width, dst, ldd, vec);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;

@@ -24,8 +24,10 @@ references and forms dropout(X) W1 for them itself; in the backward pass only
 the class-width rows of dP2 and the sign bits of the remote rows of H' travel
 (96 bytes per row instead of 1 KiB at hidden 256) and the gated product
 dP2 W2^T is formed locally.  Same operations in the same order on the same
-numbers, so the result does not depend on the mode.  Weight gradients and the
-loss are all-reduced; Adam runs replicated.
+numbers, so the result does not depend on the mode.  Of the halo rows of the
+loss gradient dZ only the labelled ones travel (the others are exactly zero and
+stay zero in a resident halo buffer).  Weight gradients and the loss are
+all-reduced; Adam runs replicated.
 
 ``order="aggregate_first"`` (opt-in) evaluates the first layer as
 (A_hat X') W1 instead of A_hat (X' W1) -- the same sum, associated the other
@@ -41,6 +43,12 @@ import math
 import torch
 
 from . import ops as _hip_ops
+
+
+class _SubPlan(object):
+    """The part of a halo plan an exchange needs (send_idx, per-peer counts), for a
+    subset of the plan's rows."""
+    __slots__ = ("send_idx", "send_counts", "recv_counts", "n_send", "n_halo", "halo_pos", "send_buf", "recv_buf")
 
 
 class FullBatchGCN(object):
@@ -136,9 +144,11 @@ class FullBatchGCN(object):
                 self.xd_halo = e(nh, self.f) if self.keep < 1.0 else None
             else:
                 self.recompute = self._setup_recompute(halo_mode)
+            self._setup_label_exchange()
         else:
             self.slab = None
             self.recompute = False
+            self.dz_plan = None
         # sign bits of H' written by the SpMM that produces it: the backward gate
         # then reads 1 bit per element instead of the element
         sup_bits = getattr(self.k, "spmm_supports_sign_bits", None)
@@ -188,6 +198,60 @@ class FullBatchGCN(object):
         self.dp2_send, self.dp2_halo = e(ns, self.c), e(nh, self.c)
         self._bits_work = None
         return True
+
+    # ------------------------------------------- loss gradient: labelled rows only
+    def _setup_label_exchange(self):
+        """dZ = (softmax - y) * mask / total is exactly zero outside the labelled
+        rows, so of the halo rows of dZ only the labelled ones travel; the others
+        stay zero in a resident halo buffer.  Set-up: every owner tells its
+        requesters which of the requested rows are labelled (one exchange of a
+        0/1 column through the backward plan); per step the labelled rows are
+        exchanged packed and placed with gcnx_scatter_rows_f32.  The product that
+        reads them is unchanged, so are its sums."""
+        plan = self.plan_bwd
+        scatter = getattr(self.k, "scatter_rows", None)
+        self.dz_plan = None
+        if scatter is None:
+            return
+        flag = (self.ymask != 0).to(torch.float32).view(-1, 1).contiguous()
+        got = torch.zeros((max(plan.n_halo, 1), 1), dtype=torch.float32, device=self.dev)
+        self._exchange_rows(plan, flag, got)
+
+        def per_peer(marks, counts):
+            out, lo = [], 0
+            m = marks.to("cpu")
+            for c in counts:
+                out.append(int(m[lo:lo + c].sum().item()))
+                lo += c
+            return out
+
+        sub = _SubPlan()
+        if plan.n_send:
+            lab_s = flag[plan.send_idx.long(), 0] != 0
+            sub.send_idx = plan.send_idx[lab_s].contiguous()
+            sub.send_counts = per_peer(lab_s, plan.send_counts)
+        else:
+            sub.send_idx = torch.empty(0, dtype=torch.int32, device=self.dev)
+            sub.send_counts = [0] * self.world
+        lab_h = got[:plan.n_halo, 0] != 0
+        sub.halo_pos = torch.nonzero(lab_h).view(-1).to(torch.int32).contiguous()
+        sub.recv_counts = per_peer(lab_h, plan.recv_counts)
+        sub.n_send, sub.n_halo = int(sub.send_idx.numel()), int(sub.halo_pos.numel())
+        sub.send_buf = torch.empty((max(sub.n_send, 1), self.c), dtype=torch.float32, device=self.dev)
+        sub.recv_buf = torch.empty((max(sub.n_halo, 1), self.c), dtype=torch.float32, device=self.dev)
+        # halo rows of dZ: zero for good, except the labelled ones (rewritten every step)
+        self.dz_halo = torch.zeros((max(plan.n_halo, 1), self.c), dtype=torch.float32, device=self.dev)
+        self.dz_plan = sub
+
+    def _aggregate_loss_gradient(self):
+        """dP2 = A^T [dZ; halo rows of dZ] with only the labelled halo rows fetched."""
+        sub, plan = self.dz_plan, self.plan_bwd
+        work = self._exchange_start(sub, self.dz, 0, self.c, sub.send_buf[:sub.n_send], sub.recv_buf[:sub.n_halo])
+        if work is not None:
+            work.wait()
+        if sub.n_halo:
+            self.k.scatter_rows(sub.recv_buf[:sub.n_halo], sub.halo_pos, self.dz_halo)
+        self.k.spmm(plan.csr, self.dz, out=self.dp2, b2=self.dz_halo[:plan.n_halo] if plan.n_halo else None)
 
     def _exchange_rows(self, plan, src, dst):
         """dst[i, :] = row plan.need[i] of the global matrix whose local rows are
@@ -375,7 +439,10 @@ class FullBatchGCN(object):
         out = self.loss(want_grad=True)
         keep = self.keep
         # layer 2
-        self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
+        if self.dz_plan is not None:
+            self._aggregate_loss_gradient()                                  # A^T dZ, labelled halo rows only
+        else:
+            self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
         dp2_work = None
         if self.recompute:
             plan = self.plan

@@ -558,6 +558,22 @@ def gather_rows(src, idx, out):
     return out
 
 
+def scatter_rows(src, idx, out):
+    """``out[idx[j], :] = src[j, :]`` for distinct ``idx`` (int32 on the device);
+    the other rows of ``out`` keep their contents."""
+    lib = _lib.load()
+    _check_dense(src, "src")
+    _check_dense(out, "out")
+    if idx.dtype != torch.int32 or idx.device != src.device or not idx.is_contiguous():
+        raise ValueError("idx must be a contiguous int32 tensor on src's device")
+    if src.shape[0] != idx.numel() or out.shape[1] != src.shape[1]:
+        raise ValueError("src must be [len(idx), width of out]")
+    with torch.cuda.device(src.device):
+        _lib.check(lib.gcnx_scatter_rows_f32(idx.numel(), _ptr(idx), _ptr(src), src.stride(0),
+                                             src.shape[1], _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 def philox_uniform(shape, lo, hi, seed, offset, device):
     """fp32 tensor of U(lo, hi) values, element i a pure function of
     (seed, offset + i) (synthetic benchmark inputs)."""

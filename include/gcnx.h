@@ -241,7 +241,11 @@ int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chunk_row,
  * n_local + position in need[].  GCNX_ERR_WORKSPACE if need_cap is too small
  * (*h_n_need then holds the required size).
  * gcnx_gather_rows_f32: dst[j, 0:width] = src[idx[j], 0:width] (packs the rows
- * a peer asked for into a contiguous send buffer). */
+ * a peer asked for into a contiguous send buffer).
+ * gcnx_scatter_rows_f32: dst[idx[j], 0:width] = src[j, 0:width] for distinct
+ * idx[j] (places received rows into a resident halo buffer whose other rows
+ * keep their contents: the labelled rows of the loss gradient, the only ones
+ * that are not exactly zero). */
 size_t gcnx_halo_plan_workspace_bytes(int64_t n_cols_global);
 int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
                    int32_t *col_remapped, int32_t *need, int64_t need_cap,
@@ -249,6 +253,9 @@ int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
 int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                          int64_t lds, int32_t width, float *dst, int64_t ldd,
                          void *stream);
+int gcnx_scatter_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
+                          int64_t lds, int32_t width, float *dst, int64_t ldd,
+                          void *stream);
 
 /* ---- the exchange itself, over RCCL (xGMI inside a node) ------------------
  * No counterpart in the reference (single process).  One process per GPU; every

@@ -86,6 +86,10 @@ class OracleKernels(object):
         out.copy_(src[idx.long()])
         return out
 
+    def scatter_rows(self, src, idx, out):
+        out[idx.long()] = src
+        return out
+
     def spmm_supports_sign_bits(self, width):
         return width % 32 == 0
 

@@ -56,6 +56,11 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
         kernels=OracleKernels(), halo_mode=halo_mode, order=order, dropout=dropout)
     if world > 1:
         assert eng.recompute == (halo_mode == "recompute" and order == "reference")
+        # the halo rows of the loss gradient that travel are exactly the labelled ones
+        need = eng.plan_bwd.need.numpy().astype(np.int64)
+        assert eng.dz_plan is not None and eng.dz_plan.n_halo == int(lmask[need].sum())
+        assert np.array_equal(eng.dz_plan.halo_pos.numpy(), np.nonzero(lmask[need])[0])
+        assert sum(eng.dz_plan.recv_counts) == eng.dz_plan.n_halo < eng.plan_bwd.n_halo
     # 16 classes and a hidden width that is a multiple of 64: the backward product
     # with the factored operand (dP2 rows + sign words, local and halo)
     assert eng.factored_bwd == (classes == 16 and hidden % 64 == 0 and order == "reference" and

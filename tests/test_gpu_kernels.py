@@ -978,3 +978,22 @@ def test_relu_epilogues_propagate_nan(env):
         hit[r[c == 7]] = True
         got = torch.isnan(out).all(dim=1).cpu().numpy()
         assert np.array_equal(got, hit), (n, nnz, w)
+
+
+@pytest.mark.parametrize("width,pitch", [(16, 16), (5, 7), (64, 80)])
+def test_scatter_rows_places_rows_and_leaves_the_rest(env, width, pitch):
+    """gcnx_scatter_rows_f32: out[idx[j]] = src[j] for distinct idx, other rows
+    untouched (16-byte path and scalar path), the inverse of gather_rows."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    g = torch.Generator().manual_seed(width)
+    n, m = 5000, 1237
+    idx = torch.randperm(n, generator=g)[:m].to(torch.int32).to(dev)
+    src = torch.randn(m, pitch, generator=g).to(dev)[:, :width]
+    out = torch.full((n, pitch), 3.0, device=dev)[:, :width]
+    ops.scatter_rows(src, idx, out)
+    want = torch.full((n, width), 3.0, device=dev)
+    want[idx.long()] = src
+    assert torch.equal(out, want)
+    back = torch.empty((m, width), device=dev)
+    ops.gather_rows(out.contiguous(), idx, back)
+    assert torch.equal(back, src)
