@@ -332,6 +332,7 @@ def main():
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
                              if comm is not None else "torch.distributed " + args.backend),
                 "order": args.order, "dense_arith": args.dense_arith,
+                "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),
                 "spmm_per_step": ("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
                                   if args.order == "reference" else
                                   "1 x width %d + 2 x width %d" % (args.features, args.classes)),

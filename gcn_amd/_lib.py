@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCNX_LIB overrides the path (kernel-variant experiments during development)
 LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 SPMM_STATIC_SCRATCH_BYTES = 32 << 20   # GCNX_SPMM_STATIC_SCRATCH_BYTES of include/gcnx.h
 
 OK = 0
@@ -46,7 +46,7 @@ class CsrStruct(C.Structure):
     """Mirror of ``struct gcnx_csr``."""
     _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64),
                 ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("val", C.c_void_p),
-                ("spmm_chunk", C.c_int32)]
+                ("spmm_chunk", C.c_int32), ("gather_keep", C.c_void_p)]
 
 
 _i32, _i64, _u64, _f32, _f64 = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -96,6 +96,8 @@ SIGNATURES = {
     "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
     "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_scatter_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "gcnx_csr_column_degrees": (_int, [_csr_p, _p, _p]),
+    "gcnx_csr_gather_keep": (_int, [_csr_p, _p, _i32, _p, _p]),
     "gcnx_comm_available": (_int, []),
     "gcnx_comm_unique_id": (_int, [_p]),
     "gcnx_comm_create": (_int, [_i32, _i32, _p, C.POINTER(C.c_void_p)]),

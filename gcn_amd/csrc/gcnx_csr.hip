@@ -269,6 +269,27 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(int64_t n_idx,
   }
 }
 
+__global__ __launch_bounds__(kBlock) void column_degree_kernel(int64_t nnz, const int32_t *__restrict__ col_idx,
+                                                              int32_t *__restrict__ degree) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(degree + col_idx[k], 1);     // integer counts: the order of the additions does not matter
+}
+
+// one wavefront per 64 nonzeros: the ballot of (degree of my column >= min_degree) IS the word
+__global__ __launch_bounds__(kBlock) void gather_keep_kernel(int64_t nnz, const int32_t *__restrict__ col_idx,
+                                                            const int32_t *__restrict__ degree, int32_t min_degree,
+                                                            unsigned long long *__restrict__ keep) {
+  const int64_t words = (nnz + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < words;
+       w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t k = w * 64 + lane;
+    const bool hot = k < nnz && degree[col_idx[k]] >= min_degree;
+    const unsigned long long bits = __ballot(hot);
+    if (lane == 0) keep[w] = bits;
+  }
+}
+
 }  // namespace gcnx
 
 using namespace gcnx;
@@ -357,6 +378,33 @@ extern "C" int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const flo
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
                      n_idx, idx, src, lds, width, dst, ldd, vec);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_csr_column_degrees(const gcnx_csr *a, int32_t *degree, void *stream) {
+  GCNX_REQUIRE(a && a->n_cols >= 0 && a->nnz >= 0, GCNX_ERR_INVALID_ARG, "column_degrees: bad matrix");
+  if (a->n_cols == 0) return GCNX_OK;
+  GCNX_REQUIRE(degree && (a->nnz == 0 || a->col_idx), GCNX_ERR_INVALID_ARG, "column_degrees: null array");
+  hipStream_t st = as_stream(stream);
+  GCNX_CHECK_HIP(hipMemsetAsync(degree, 0, (size_t)a->n_cols * sizeof(int32_t), st));
+  if (a->nnz == 0) return GCNX_OK;
+  int64_t blocks = ceil_div(a->nnz, kBlock);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(column_degree_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a->nnz, a->col_idx, degree);
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_csr_gather_keep(const gcnx_csr *a, const int32_t *degree, int32_t min_degree,
+                                    uint64_t *keep, void *stream) {
+  GCNX_REQUIRE(a && a->nnz >= 0, GCNX_ERR_INVALID_ARG, "gather_keep: bad matrix");
+  if (a->nnz == 0) return GCNX_OK;
+  GCNX_REQUIRE(a->col_idx && degree && keep, GCNX_ERR_INVALID_ARG, "gather_keep: null array");
+  int64_t blocks = ceil_div(ceil_div(a->nnz, 64), kBlock / 64);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(gather_keep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a->nnz,
+                     a->col_idx, degree, min_degree, reinterpret_cast<unsigned long long *>(keep));
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

@@ -70,6 +70,9 @@ struct SpmmArgs {
   const int32_t *col_idx;
   const float *val;
   const int32_t *chunk_row;
+  // nullable cache hint of the wide kernel: bit (k % 64) of word k / 64 clear <=> the
+  // operand row of nonzero k is read with a streaming (non-temporal) load
+  const unsigned long long *keep_bits;
   const float *B;
   int64_t ldb;
   const float *B2;   // rows >= split come from here (halo rows received from peers)
@@ -242,6 +245,14 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
     const float vals = vals_n;
     if (kb + kWave < nk) load_batch(kb + kWave, cols_n, vals_n);
     const int jn = (nk - kb) < kWave ? (nk - kb) : kWave;
+    // keep bits of this batch of 64 nonzeros (chunks start at multiples of 64): one
+    // wavefront-uniform word; without a hint every row is kept
+    unsigned long long keep = ~0ull;
+    if (a.keep_bits) {
+      const unsigned long long w = a.keep_bits[(n0 + kb) >> 6];
+      keep = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+    }
     for (int j = 0; j < jn; j += U) {
       V b[U];
 #pragma unroll
@@ -251,7 +262,16 @@ __global__ __launch_bounds__(kBlock, GCNX_WIDE_WAVES) void spmm_chunk_kernel(con
         const float *src = (cc < a.split ? a.B + (int64_t)cc * a.ldb
                                          : a.B2 + (int64_t)(cc - a.split) * a.ldb2) + col0;
         b[u] = V(0.0f);
-        if (active) b[u] = vload<VEC>(src);
+        if (active) {
+          if ((keep >> jj) & 1ull) {
+            b[u] = vload<VEC>(src);
+          } else {
+            // a rarely referenced row: streamed, so that it does not evict the rows worth keeping
+            const float *cold = src;
+            asm volatile("" : "+v"(cold));      // keeps the two loads (and their cache policies) apart
+            b[u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(cold));
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1247,6 +1267,7 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   k.col_idx = a->col_idx;
   k.val = a->val;
   k.chunk_row = chunk_row;
+  k.keep_bits = reinterpret_cast<const unsigned long long *>(a->gather_keep);
   k.B = B;
   k.ldb = ldb;
   k.B2 = B2;

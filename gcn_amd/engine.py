@@ -149,6 +149,9 @@ class FullBatchGCN(object):
             self.slab = None
             self.recompute = False
             self.dz_plan = None
+        # the hidden-width forward product gathers 4 h bytes per nonzero from an operand
+        # far larger than the caches: tell the kernel which rows are worth keeping there
+        self._hint_forward_matrix()
         # sign bits of H' written by the SpMM that produces it: the backward gate
         # then reads 1 bit per element instead of the element
         sup_bits = getattr(self.k, "spmm_supports_sign_bits", None)
@@ -167,6 +170,18 @@ class FullBatchGCN(object):
         sup_f = getattr(self.k, "spmm_supports_factored", None)
         self.factored_bwd = bool(not agg_first and self.hbits is not None and self.keep > 0.0 and sup_f is not None and
                                  sup_f(self.h, self.c))
+
+    def _hint_forward_matrix(self):
+        width = self.f if self.order == "aggregate_first" else self.h
+        if self.world == 1:
+            m = self.a
+        elif self.order == "aggregate_first" or self.recompute:
+            m = self.plan.csr                 # one full-width launch over [local | halo] columns
+        else:
+            return                            # exchanged in 64-column slabs: the narrow kernel
+        hint = getattr(m, "set_gather_hint", None)
+        if hint is not None and width > 128 and m.n_cols * width * 4 > (1 << 30) and m.nnz > (1 << 24):
+            hint(width * 4)
 
     # --------------------------------------------------- halo rows by recompute
     def _recompute_feasible(self, halo_mode):

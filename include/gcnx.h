@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GCNX_ABI_VERSION 2
+#define GCNX_ABI_VERSION 3
 
 typedef enum gcnx_status {
   GCNX_OK = 0,
@@ -54,7 +54,14 @@ typedef enum gcnx_status {
  * otherwise chunks of 64..512 nonzeros per wavefront by matrix size); 64, 128,
  * 256 or 512 sends every product with this matrix down the chunk kernels with
  * that many nonzeros per wavefront (other values are rounded up to the next of
- * these).  The library keeps no dispatch state of its own. */
+ * these).  The library keeps no dispatch state of its own.
+ * gather_keep (nullable) is a cache hint for products whose dense operand is
+ * wider than 128 columns and far larger than the caches: bit k % 64 of word
+ * k / 64 says that the operand row of nonzero k is worth keeping cached (its
+ * column is referenced often); rows of nonzeros whose bit is clear are read
+ * with streaming (non-temporal) loads, so that they do not evict the rows that
+ * are.  It changes which cache lines survive, never a result.  Build it with
+ * gcnx_csr_column_degrees + gcnx_csr_gather_keep. */
 typedef struct gcnx_csr {
   int64_t n_rows;
   int64_t n_cols;
@@ -63,6 +70,7 @@ typedef struct gcnx_csr {
   const int32_t *col_idx; /* [nnz] */
   const float *val;       /* [nnz] */
   int32_t spmm_chunk;     /* dispatch hint, see above; 0 = chosen by the library */
+  const uint64_t *gather_keep; /* [ceil(nnz / 64)] or NULL, see above */
 } gcnx_csr;
 
 /* Dropout fused into the epilogue of a product (replaces tf.nn.dropout on the
@@ -253,6 +261,13 @@ int gcnx_halo_plan(const gcnx_csr *a, int64_t row_begin, int64_t n_local,
 int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                          int64_t lds, int32_t width, float *dst, int64_t ldd,
                          void *stream);
+/* Cache hint of the wide SpMM (gcnx_csr::gather_keep; no counterpart in the
+ * reference).  gcnx_csr_column_degrees: degree[c] = number of nonzeros in column c
+ * (degree is zeroed first).  gcnx_csr_gather_keep: keep bit of nonzero k =
+ * (degree[col_idx[k]] >= min_degree); bits past nnz in the last word are clear. */
+int gcnx_csr_column_degrees(const gcnx_csr *a, int32_t *degree, void *stream);
+int gcnx_csr_gather_keep(const gcnx_csr *a, const int32_t *degree, int32_t min_degree,
+                         uint64_t *keep, void *stream);
 int gcnx_scatter_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                           int64_t lds, int32_t width, float *dst, int64_t ldd,
                           void *stream);

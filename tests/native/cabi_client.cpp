@@ -79,7 +79,7 @@ int main() {
   void *ws = dev_alloc<char>(ws_bytes);
   GCNX_OK_(gcnx_csr_from_coo(n_rows, n_cols, nnz, d_row, d_col, 1, d_val, 1, d_rp, d_ci, d_v, nullptr, ws,
                              ws_bytes, stream));
-  gcnx_csr a = {n_rows, n_cols, nnz, d_rp, d_ci, d_v};
+  gcnx_csr a = {n_rows, n_cols, nnz, d_rp, d_ci, d_v, 0, nullptr};
   int32_t *d_chunk = dev_alloc<int32_t>((size_t)gcnx_spmm_num_chunks(nnz) + 1);
   GCNX_OK_(gcnx_spmm_chunk_table(&a, d_chunk, stream));
   size_t sp_bytes = gcnx_spmm_workspace_bytes(&a, width);

@@ -997,3 +997,39 @@ def test_scatter_rows_places_rows_and_leaves_the_rest(env, width, pitch):
     back = torch.empty((m, width), device=dev)
     ops.gather_rows(out.contiguous(), idx, back)
     assert torch.equal(back, src)
+
+
+@pytest.mark.parametrize("chunk", [64, 512])
+def test_gather_hint_changes_no_result(env, chunk):
+    """gcnx_csr::gather_keep: the column degrees and the keep bits against numpy,
+    and the wide SpMM with rows of rarely referenced columns streamed
+    (non-temporal loads) against the same product without the hint: same bits,
+    with every row streamed and with every row kept as well."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(chunk)
+    n, nnz, w = 6000, 150001, 256
+    r = rng.randint(0, n, nnz).astype(np.int32)
+    c = np.minimum((rng.pareto(1.2, nnz) * 20).astype(np.int64), n - 1).astype(np.int32)    # a few hot columns
+    v = rng.standard_normal(nnz).astype(np.float32)
+    a = Csr.from_coo(torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(v).to(dev), (n, n),
+                     device=dev)
+    a.spmm_chunk = chunk                                  # the chunk kernels (the small-matrix kernel has no hint)
+    b = torch.randn(n, w, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = ops.spmm(a, b, relu=True)
+    deg = a.column_degrees().cpu().numpy()
+    assert np.array_equal(deg, np.bincount(c, minlength=n))
+    cols = a.col_idx.cpu().numpy()
+    for thr in (None, 2, 40, 10 ** 9):
+        used = a.set_gather_hint(w * 4, budget_bytes=64 * w * 4, min_degree=thr)
+        if thr is None:
+            # the smallest threshold whose columns fit the budget of 64 rows
+            assert (deg >= used).sum() <= 64 and (used <= 2 or (deg >= used - 1).sum() > 64)
+        words = a.gather_keep.cpu().numpy().view(np.uint64)
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:a.nnz].astype(bool)
+        assert np.array_equal(bits, deg[cols] >= used)
+        assert not np.unpackbits(words.view(np.uint8), bitorder="little")[a.nnz:].any()
+        got = ops.spmm(a, b, relu=True)
+        assert torch.equal(got, ref), thr
+    a.clear_gather_hint()
+    assert torch.equal(ops.spmm(a, b, relu=True), ref)
