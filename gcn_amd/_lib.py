@@ -98,6 +98,8 @@ SIGNATURES = {
     "gcnx_scatter_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_csr_column_degrees": (_int, [_csr_p, _p, _p]),
     "gcnx_csr_gather_keep": (_int, [_csr_p, _p, _i32, _p, _p]),
+    "gcnx_csr_degree_threshold_workspace_bytes": (_sz, []),
+    "gcnx_csr_degree_threshold": (_int, [_p, _i64, _i64, _p, _p, _sz, _p]),
     "gcnx_comm_available": (_int, []),
     "gcnx_comm_unique_id": (_int, [_p]),
     "gcnx_comm_create": (_int, [_i32, _i32, _p, C.POINTER(C.c_void_p)]),

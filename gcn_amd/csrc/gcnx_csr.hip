@@ -275,6 +275,22 @@ __global__ __launch_bounds__(kBlock) void column_degree_kernel(int64_t nnz, cons
     atomicAdd(degree + col_idx[k], 1);     // integer counts: the order of the additions does not matter
 }
 
+// how many columns have degree d, for d < kDegreeBins - 1; the last bin collects the rest
+constexpr int kDegreeBins = 4096;
+__global__ __launch_bounds__(kBlock) void degree_histogram_kernel(int64_t n, const int32_t *__restrict__ degree,
+                                                                 int32_t *__restrict__ bins) {
+  __shared__ int32_t local[kDegreeBins];
+  for (int i = threadIdx.x; i < kDegreeBins; i += blockDim.x) local[i] = 0;
+  __syncthreads();
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = degree[c];
+    atomicAdd(local + (d < kDegreeBins - 1 ? (d < 0 ? 0 : d) : kDegreeBins - 1), 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDegreeBins; i += blockDim.x)
+    if (local[i]) atomicAdd(bins + i, local[i]);
+}
+
 // one wavefront per 64 nonzeros: the ballot of (degree of my column >= min_degree) IS the word
 __global__ __launch_bounds__(kBlock) void gather_keep_kernel(int64_t nnz, const int32_t *__restrict__ col_idx,
                                                             const int32_t *__restrict__ degree, int32_t min_degree,
@@ -393,6 +409,39 @@ extern "C" int gcnx_csr_column_degrees(const gcnx_csr *a, int32_t *degree, void 
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(column_degree_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a->nnz, a->col_idx, degree);
   GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+extern "C" size_t gcnx_csr_degree_threshold_workspace_bytes(void) { return kDegreeBins * sizeof(int32_t); }
+
+extern "C" int gcnx_csr_degree_threshold(const int32_t *degree, int64_t n_cols, int64_t max_columns,
+                                         int32_t *h_min_degree, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(n_cols >= 0 && max_columns >= 0 && h_min_degree, GCNX_ERR_INVALID_ARG, "degree_threshold: bad argument");
+  *h_min_degree = 2;
+  if (n_cols == 0) return GCNX_OK;
+  GCNX_REQUIRE(degree, GCNX_ERR_INVALID_ARG, "degree_threshold: null degrees");
+  GCNX_REQUIRE(ws && ws_bytes >= kDegreeBins * sizeof(int32_t), GCNX_ERR_WORKSPACE,
+               "degree_threshold: workspace of %zu bytes required, got %zu", kDegreeBins * sizeof(int32_t), ws_bytes);
+  hipStream_t st = as_stream(stream);
+  int32_t *bins = static_cast<int32_t *>(ws);
+  GCNX_CHECK_HIP(hipMemsetAsync(bins, 0, kDegreeBins * sizeof(int32_t), st));
+  int64_t blocks = ceil_div(n_cols, (int64_t)kBlock * 16);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(degree_histogram_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, n_cols, degree, bins);
+  GCNX_CHECK_LAUNCH();
+  static thread_local int32_t host[kDegreeBins];
+  GCNX_CHECK_HIP(hipMemcpyAsync(host, bins, sizeof(host), hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  // the smallest d >= 2 with (columns of degree >= d) <= max_columns; degrees from
+  // kDegreeBins - 1 on share the last bin, so the answer is capped there
+  int64_t at_least = 0;
+  int32_t d = kDegreeBins - 1;
+  for (; d >= 2; --d) {
+    if (at_least + host[d] > max_columns) break;
+    at_least += host[d];
+  }
+  *h_min_degree = d + 1 > kDegreeBins - 1 ? kDegreeBins - 1 : d + 1;
   return GCNX_OK;
 }
 

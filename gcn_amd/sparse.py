@@ -124,10 +124,12 @@ class Csr(object):
         lib = _lib.load()
         deg = self.column_degrees()
         if min_degree is None:
-            counts = torch.bincount(deg.long())                       # columns per degree
-            at_least = counts.flip(0).cumsum(0).flip(0)               # columns of degree >= d
-            fits = torch.nonzero(at_least * int(row_bytes) <= int(budget_bytes)).view(-1)
-            min_degree = int(fits[0].item()) if fits.numel() else int(counts.numel())
+            found = C.c_int32(0)
+            with torch.cuda.device(self.device):
+                ws = WORKSPACE.get(lib.gcnx_csr_degree_threshold_workspace_bytes(), self.device)
+                _lib.check(lib.gcnx_csr_degree_threshold(_ptr(deg), self.n_cols, int(budget_bytes) // int(row_bytes),
+                                                         C.byref(found), _ptr(ws), ws.numel(), _stream()))
+            min_degree = found.value
         min_degree = max(int(min_degree), 2)
         keep = torch.empty((self.nnz + 63) // 64, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):

@@ -266,6 +266,12 @@ int gcnx_gather_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
  * (degree is zeroed first).  gcnx_csr_gather_keep: keep bit of nonzero k =
  * (degree[col_idx[k]] >= min_degree); bits past nnz in the last word are clear. */
 int gcnx_csr_column_degrees(const gcnx_csr *a, int32_t *degree, void *stream);
+/* *h_min_degree (host) = the smallest degree d >= 2 such that at most max_columns
+ * columns have degree >= d (capped at 4095): the threshold that makes the kept
+ * rows fit a cache budget of max_columns rows.  Synchronises the stream. */
+size_t gcnx_csr_degree_threshold_workspace_bytes(void);
+int gcnx_csr_degree_threshold(const int32_t *degree, int64_t n_cols, int64_t max_columns,
+                              int32_t *h_min_degree, void *ws, size_t ws_bytes, void *stream);
 int gcnx_csr_gather_keep(const gcnx_csr *a, const int32_t *degree, int32_t min_degree,
                          uint64_t *keep, void *stream);
 int gcnx_scatter_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
