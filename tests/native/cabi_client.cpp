@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -111,6 +112,55 @@ int main() {
   // ---- a wrong call comes back as a status, not as an abort ----------------
   if (gcnx_spmm_csr_f32(&a, d_chunk, d_b, width, d_c, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 0,
                         sp_ws, 16, stream) != GCNX_ERR_WORKSPACE) return 1;
+
+  // ---- cache hint: column degrees -> threshold -> keep bits; a 256-column product must not change ----
+  {
+    const int32_t ww = 256;
+    int32_t *d_deg = dev_alloc<int32_t>((size_t)n_cols);
+    uint64_t *d_keep = dev_alloc<uint64_t>((size_t)((nnz + 63) / 64));
+    const size_t th_bytes = gcnx_csr_degree_threshold_workspace_bytes();
+    void *th_ws = dev_alloc<char>(th_bytes);
+    std::vector<float> bw((size_t)n_cols * ww);
+    for (auto &v : bw) v = (float)urand();
+    float *d_bw = dev_alloc<float>(bw.size());
+    float *d_c1 = dev_alloc<float>((size_t)n_rows * ww), *d_c2 = dev_alloc<float>((size_t)n_rows * ww);
+    if (!d_deg || !d_keep || !th_ws || !d_bw || !d_c1 || !d_c2) return 2;
+    HIP_OK(hipMemcpy(d_bw, bw.data(), bw.size() * 4, hipMemcpyHostToDevice));
+    GCNX_OK_(gcnx_csr_column_degrees(&a, d_deg, stream));
+    int32_t min_degree = 0;
+    GCNX_OK_(gcnx_csr_degree_threshold(d_deg, n_cols, n_cols / 8, &min_degree, th_ws, th_bytes, stream));
+    GCNX_OK_(gcnx_csr_gather_keep(&a, d_deg, min_degree, d_keep, stream));
+    std::vector<int32_t> deg((size_t)n_cols);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(deg.data(), d_deg, deg.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> want_deg((size_t)n_cols, 0);
+    for (int64_t k = 0; k < nnz; ++k) ++want_deg[col[k]];
+    int64_t kept_cols = 0;
+    for (int64_t c2 = 0; c2 < n_cols; ++c2) {
+      if (deg[c2] != want_deg[c2]) return 1;
+      kept_cols += deg[c2] >= min_degree;
+    }
+    if (min_degree < 2 || kept_cols > n_cols / 8) return 1;
+    gcnx_csr hinted = a;
+    hinted.spmm_chunk = 64;                 // the chunk kernel (the small-matrix kernel reads no hint)
+    hinted.gather_keep = d_keep;
+    gcnx_csr plain = hinted;
+    plain.gather_keep = nullptr;
+    const size_t hb = gcnx_spmm_workspace_bytes(&hinted, ww);
+    void *h_ws = dev_alloc<char>(hb);
+    if (!h_ws) return 2;
+    GCNX_OK_(gcnx_spmm_csr_f32(&plain, d_chunk, d_bw, ww, d_c1, ww, ww, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 1, h_ws, hb,
+                               stream));
+    GCNX_OK_(gcnx_spmm_csr_f32(&hinted, d_chunk, d_bw, ww, d_c2, ww, ww, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 1, h_ws, hb,
+                               stream));
+    std::vector<float> c1v((size_t)n_rows * ww), c2v((size_t)n_rows * ww);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(c1v.data(), d_c1, c1v.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(c2v.data(), d_c2, c2v.size() * 4, hipMemcpyDeviceToHost));
+    if (std::memcmp(c1v.data(), c2v.data(), c1v.size() * 4) != 0) return 1;
+    std::printf("gather hint: columns of degree >= %d kept (%lld of %lld), 256-column product unchanged\n", min_degree,
+                (long long)kept_cols, (long long)n_cols);
+  }
 
   // ---- dense product ---------------------------------------------------------
   std::vector<float> ha((size_t)M * K), hb((size_t)K * N), hc((size_t)M * N);
