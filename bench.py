@@ -290,6 +290,10 @@ def main():
 
     def barrier():
         if world > 1:
+            # drain this rank's streams first: the library's communicator and
+            # torch's are two RCCL communicators in one process, and nothing of
+            # the first should still be in flight when the second one's barrier goes out
+            torch.cuda.synchronize()
             dist.barrier(group=group)
         torch.cuda.synchronize()
 

@@ -1,6 +1,8 @@
-"""Development probe: phase timing of spmm_factored_mfma_kernel from a library
-built with -DFACT_TRACE (GCNX_LIB=<that library>).  Prints the mean cycle
-counts per round of 4096 wavefronts in the middle of the grid."""
+"""Development probe: phase timing of spmm_factored_mfma_kernel.  Needs a
+library built from gcnx_spmm.hip with tools/probe/factored_trace.patch applied
+and -DFACT_TRACE (load it with GCNX_LIB=<that library>); the shipped library
+carries no trace code.  Prints the mean cycle counts per round of 4096
+wavefronts in the middle of the grid (RMAT-24, width 256)."""
 import ctypes as C
 import os
 import sys
