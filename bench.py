@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="several GPUs over RCCL: per-step halo exchange / all-reduce through the C ABI "
                          "(gcnx_halo_allgather_f32, default) or through torch.distributed")
+    ap.add_argument("--dense-loss-gradient", action="store_true",
+                    help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
+                         "labelled columns only (the other rows of dZ are exactly zero; same result)")
     args = ap.parse_args()
 
     t_start = time.time()
@@ -240,7 +243,13 @@ def main():
             note("C-ABI communicator up, self-check passed")
     model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                        row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
-                       slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm)
+                       slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
+                       sparse_loss_gradient=not args.dense_loss_gradient)
+    nnz_dz = torch.tensor([model.loss_gradient_nnz()], dtype=torch.int64,
+                          device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(nnz_dz, group=group)
+    nnz_dz_global = int(nnz_dz.item())
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -317,7 +326,8 @@ def main():
     loss_acc = out.cpu().tolist()
 
     if rank == 0:
-        units = model.spmm_units_per_step(nnz_global)
+        # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
+        units = model.spmm_units_per_step(nnz_global, nnz_dz_global)
         result = {
             "metric": "GCN SpMM nnz*F/s (full-batch epoch: fwd + bwd + Adam)",
             "value": units * args.steps / dt,
@@ -336,10 +346,14 @@ def main():
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
                              if comm is not None else "torch.distributed " + args.backend),
                 "order": args.order, "dense_arith": args.dense_arith,
+                "nnz_loss_gradient_product": nnz_dz_global,
                 "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),
-                "spmm_per_step": ("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
-                                  if args.order == "reference" else
-                                  "1 x width %d + 2 x width %d" % (args.features, args.classes)),
+                "spmm_per_step": (("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
+                                   if args.order == "reference" else
+                                   "1 x width %d + 2 x width %d" % (args.features, args.classes)) +
+                                  ("" if nnz_dz_global == nnz_global else
+                                   "; A_hat^T dZ over the %d nonzeros of the labelled columns (dZ is zero elsewhere), "
+                                   "counted as such in value" % nnz_dz_global)),
             },
             "epoch_ms": dt / args.steps * 1e3,
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],

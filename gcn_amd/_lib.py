@@ -98,6 +98,9 @@ SIGNATURES = {
     "gcnx_scatter_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_csr_column_degrees": (_int, [_csr_p, _p, _p]),
     "gcnx_csr_gather_keep": (_int, [_csr_p, _p, _i32, _p, _p]),
+    "gcnx_csr_filter_workspace_bytes": (_sz, [_i64]),
+    "gcnx_csr_filter_columns_count": (_int, [_csr_p, _p, _p, _p, _p, _sz, _p]),
+    "gcnx_csr_filter_columns_fill": (_int, [_csr_p, _p, _sz, _i64, _p, _p, _p, _p]),
     "gcnx_csr_degree_threshold_workspace_bytes": (_sz, []),
     "gcnx_csr_degree_threshold": (_int, [_p, _i64, _i64, _p, _p, _sz, _p]),
     "gcnx_comm_available": (_int, []),

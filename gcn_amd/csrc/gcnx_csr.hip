@@ -306,6 +306,74 @@ __global__ __launch_bounds__(kBlock) void gather_keep_kernel(int64_t nnz, const 
   }
 }
 
+// ---- sub-matrix by column flags ---------------------------------------------
+// one wavefront per 64 nonzeros: the ballot of (my column is kept) is the keep word,
+// its population count the word's share of the output
+__global__ __launch_bounds__(kBlock) void filter_mark_kernel(int64_t nnz, int64_t n_cols,
+                                                            const int32_t *__restrict__ col_idx,
+                                                            const uint8_t *__restrict__ col_keep,
+                                                            unsigned long long *__restrict__ words,
+                                                            int64_t *__restrict__ count) {
+  const int64_t n_words = (nnz + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_words;
+       w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t k = w * 64 + lane;
+    bool on = false;
+    if (k < nnz) {
+      const int64_t c = col_idx[k];
+      on = c >= 0 && c < n_cols && col_keep[c] != 0;
+    }
+    const unsigned long long bits = __ballot(on);
+    if (lane == 0) {
+      words[w] = bits;
+      count[w] = __popcll(bits);
+    }
+  }
+}
+
+// number of kept nonzeros in slots [0, k); before[] is the exclusive scan of the words' counts
+__device__ __forceinline__ int64_t kept_before(int64_t k, const unsigned long long *__restrict__ words,
+                                               const int64_t *__restrict__ before) {
+  const int64_t w = k >> 6;
+  const int b = (int)(k & 63);
+  int64_t r = before[w];
+  if (b) r += __popcll(words[w] & ((1ull << b) - 1ull));
+  return r;
+}
+
+__global__ void filter_row_ptr_kernel(int64_t n_rows, int64_t nnz, const int64_t *__restrict__ row_ptr,
+                                      const unsigned long long *__restrict__ words,
+                                      const int64_t *__restrict__ before, int64_t *__restrict__ out_row_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_rows) return;
+  int64_t k = row_ptr[i];
+  k = k < 0 ? 0 : (k > nnz ? nnz : k);
+  out_row_ptr[i] = kept_before(k, words, before);
+}
+
+// kept nonzeros move up in order: slot k goes to before[word] + (kept slots below it in its word)
+__global__ __launch_bounds__(kBlock) void filter_fill_kernel(int64_t nnz, const int32_t *__restrict__ col_idx,
+                                                            const float *__restrict__ val,
+                                                            const unsigned long long *__restrict__ words,
+                                                            const int64_t *__restrict__ before,
+                                                            int32_t *__restrict__ out_col, float *__restrict__ out_val,
+                                                            int64_t *__restrict__ out_src) {
+  const int64_t n_words = (nnz + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_words;
+       w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const unsigned long long bits = words[w];
+    if ((bits >> lane) & 1ull) {
+      const int64_t k = w * 64 + lane;
+      const int64_t pos = before[w] + __popcll(bits & ((1ull << lane) - 1ull));
+      out_col[pos] = col_idx[k];
+      out_val[pos] = val[k];
+      if (out_src) out_src[pos] = k;
+    }
+  }
+}
+
 }  // namespace gcnx
 
 using namespace gcnx;
@@ -454,6 +522,103 @@ extern "C" int gcnx_csr_gather_keep(const gcnx_csr *a, const int32_t *degree, in
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(gather_keep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), a->nnz,
                      a->col_idx, degree, min_degree, reinterpret_cast<unsigned long long *>(keep));
+  GCNX_CHECK_LAUNCH();
+  return GCNX_OK;
+}
+
+// ---- sub-matrix by column flags: workspace = keep words | scanned counts | scan scratch
+namespace {
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+struct FilterLayout {
+  size_t words, before, temp, temp_bytes, total;
+  int64_t n_scan;   // words + 1: the last entry of the scan is the number of kept nonzeros
+};
+FilterLayout filter_layout(int64_t nnz) {
+  FilterLayout l;
+  const int64_t n_words = (nnz + 63) / 64;
+  l.n_scan = n_words + 1;
+  const size_t arr = align_up((size_t)l.n_scan * 8, 256);
+  l.words = 0;
+  l.before = arr;
+  l.temp = 2 * arr;
+  size_t t = 0;
+  int64_t *p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, t, p, p, (int64_t)0, (size_t)l.n_scan, rocprim::plus<int64_t>(),
+                                (hipStream_t)0);
+  l.temp_bytes = t;
+  l.total = l.temp + align_up(t, 256) + 256;
+  return l;
+}
+}  // namespace
+
+extern "C" size_t gcnx_csr_filter_workspace_bytes(int64_t nnz) { return nnz < 0 ? 0 : filter_layout(nnz).total; }
+
+extern "C" int gcnx_csr_filter_columns_count(const gcnx_csr *a, const uint8_t *col_keep, int64_t *out_row_ptr,
+                                             int64_t *h_nnz, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(a && h_nnz && a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0, GCNX_ERR_INVALID_ARG,
+               "filter_columns: bad argument");
+  *h_nnz = 0;
+  GCNX_REQUIRE(out_row_ptr, GCNX_ERR_INVALID_ARG, "filter_columns: null out_row_ptr");
+  hipStream_t st = as_stream(stream);
+  if (a->nnz == 0) {
+    GCNX_CHECK_HIP(hipMemsetAsync(out_row_ptr, 0, (size_t)(a->n_rows + 1) * sizeof(int64_t), st));
+    return GCNX_OK;
+  }
+  GCNX_REQUIRE(a->row_ptr && a->col_idx && col_keep, GCNX_ERR_INVALID_ARG, "filter_columns: null array");
+  const FilterLayout l = filter_layout(a->nnz);
+  GCNX_REQUIRE(ws && ws_bytes >= l.total && aligned16(ws), GCNX_ERR_WORKSPACE,
+               "filter_columns: workspace of %zu bytes (16-byte aligned) required, got %zu", l.total, ws_bytes);
+  char *w = static_cast<char *>(ws);
+  unsigned long long *words = reinterpret_cast<unsigned long long *>(w + l.words);
+  int64_t *before = reinterpret_cast<int64_t *>(w + l.before);
+  const int64_t n_words = l.n_scan - 1;
+  // the entry past the last word stays zero, so that the scan's last value is the total
+  GCNX_CHECK_HIP(hipMemsetAsync(before + n_words, 0, sizeof(int64_t), st));
+  GCNX_CHECK_HIP(hipMemsetAsync(words + n_words, 0, sizeof(unsigned long long), st));
+  int64_t blocks = ceil_div(n_words, kBlock / 64);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(filter_mark_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a->nnz, a->n_cols, a->col_idx,
+                     col_keep, words, before);
+  GCNX_CHECK_LAUNCH();
+  size_t tb = l.temp_bytes;
+  GCNX_CHECK_HIP(rocprim::exclusive_scan(w + l.temp, tb, before, before, (int64_t)0, (size_t)l.n_scan,
+                                         rocprim::plus<int64_t>(), st));
+  hipLaunchKernelGGL(filter_row_ptr_kernel, dim3((unsigned)ceil_div(a->n_rows + 1, 256)), dim3(256), 0, st,
+                     a->n_rows, a->nnz, a->row_ptr, words, before, out_row_ptr);
+  GCNX_CHECK_LAUNCH();
+  int64_t total = 0;
+  GCNX_CHECK_HIP(hipMemcpyAsync(&total, before + n_words, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  *h_nnz = total;
+  return GCNX_OK;
+}
+
+extern "C" int gcnx_csr_filter_columns_fill(const gcnx_csr *a, const void *ws, size_t ws_bytes, int64_t out_nnz,
+                                            int32_t *out_col, float *out_val, int64_t *out_src, void *stream) {
+  GCNX_REQUIRE(a && a->nnz >= 0 && out_nnz >= 0 && out_nnz <= a->nnz, GCNX_ERR_INVALID_ARG,
+               "filter_columns_fill: bad argument");
+  if (a->nnz == 0 || out_nnz == 0) return GCNX_OK;
+  GCNX_REQUIRE(a->col_idx && a->val && out_col && out_val, GCNX_ERR_INVALID_ARG, "filter_columns_fill: null array");
+  const FilterLayout l = filter_layout(a->nnz);
+  GCNX_REQUIRE(ws && ws_bytes >= l.total && aligned16(ws), GCNX_ERR_WORKSPACE,
+               "filter_columns_fill: the workspace gcnx_csr_filter_columns_count filled (%zu bytes) is required, got %zu",
+               l.total, ws_bytes);
+  hipStream_t st = as_stream(stream);
+  const char *w = static_cast<const char *>(ws);
+  const unsigned long long *words = reinterpret_cast<const unsigned long long *>(w + l.words);
+  const int64_t *before = reinterpret_cast<const int64_t *>(w + l.before);
+  const int64_t n_words = l.n_scan - 1;
+  // the caller's arrays hold out_nnz entries: it must be the count the first call returned
+  int64_t total = 0;
+  GCNX_CHECK_HIP(hipMemcpyAsync(&total, before + n_words, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  GCNX_CHECK_HIP(hipStreamSynchronize(st));
+  GCNX_REQUIRE(total == out_nnz, GCNX_ERR_INVALID_ARG,
+               "filter_columns_fill: out_nnz is %lld but the workspace holds a count of %lld", (long long)out_nnz,
+               (long long)total);
+  int64_t blocks = ceil_div(n_words, kBlock / 64);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(filter_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, a->nnz, a->col_idx, a->val,
+                     words, before, out_col, out_val, out_src);
   GCNX_CHECK_LAUNCH();
   return GCNX_OK;
 }

@@ -26,7 +26,9 @@ the class-width rows of dP2 and the sign bits of the remote rows of H' travel
 dP2 W2^T is formed locally.  Same operations in the same order on the same
 numbers, so the result does not depend on the mode.  Of the halo rows of the
 loss gradient dZ only the labelled ones travel (the others are exactly zero and
-stay zero in a resident halo buffer).  Weight gradients and the loss are
+stay zero in a resident halo buffer), and the product A_hat^T dZ runs over the
+nonzeros of the labelled columns only (a sub-matrix built once:
+``sparse_loss_gradient``).  Weight gradients and the loss are
 all-reduced; Adam runs replicated.
 
 ``order="aggregate_first"`` (opt-in) evaluates the first layer as
@@ -55,7 +57,8 @@ class FullBatchGCN(object):
     def __init__(self, a_local, x_local, labels_local, mask_local, mask_total, n_hidden, n_class,
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
-                 kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None):
+                 kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None,
+                 sparse_loss_gradient=True):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -69,7 +72,13 @@ class FullBatchGCN(object):
         (gcnx_halo_allgather_f32 / gcnx_comm_allreduce_sum_f32, RCCL bound inside
         libgcnhip.so) on the communicator's own stream; without it they go
         through torch.distributed on ``group`` (the gloo rehearsal).  The
-        set-up exchanges of the halo plan always use ``group``."""
+        set-up exchanges of the halo plan always use ``group``.
+        ``sparse_loss_gradient``: the rows of dZ outside the labelled set are
+        exactly zero (the mask multiplies the per-row loss, gcn/metrics.py:4-11), so
+        A_hat^T dZ is formed with the nonzeros of the labelled columns only -- a
+        sub-matrix built once, the label mask being fixed; every row of dP2 is
+        still written and no sum changes (False: the full matrix, zeros
+        multiplied as the reference does)."""
         self.k = kernels if kernels is not None else _hip_ops
         self.comm = comm
         self.a = a_local
@@ -149,6 +158,7 @@ class FullBatchGCN(object):
             self.slab = None
             self.recompute = False
             self.dz_plan = None
+        self._setup_loss_gradient_matrix(sparse_loss_gradient)
         # the hidden-width forward product gathers 4 h bytes per nonzero from an operand
         # far larger than the caches: tell the kernel which rows are worth keeping there
         self._hint_forward_matrix()
@@ -249,6 +259,7 @@ class FullBatchGCN(object):
             sub.send_idx = torch.empty(0, dtype=torch.int32, device=self.dev)
             sub.send_counts = [0] * self.world
         lab_h = got[:plan.n_halo, 0] != 0
+        self.dz_halo_labelled = lab_h
         sub.halo_pos = torch.nonzero(lab_h).view(-1).to(torch.int32).contiguous()
         sub.recv_counts = per_peer(lab_h, plan.recv_counts)
         sub.n_send, sub.n_halo = int(sub.send_idx.numel()), int(sub.halo_pos.numel())
@@ -258,6 +269,28 @@ class FullBatchGCN(object):
         self.dz_halo = torch.zeros((max(plan.n_halo, 1), self.c), dtype=torch.float32, device=self.dev)
         self.dz_plan = sub
 
+    def _setup_loss_gradient_matrix(self, enabled):
+        """``self.at_dz``: the matrix of the product A^T dZ restricted to the columns
+        whose dZ row can be nonzero (labelled local rows and labelled halo rows), or
+        None (the full matrix is used)."""
+        self.at_dz = None
+        filt = getattr(self.k, "csr_filter_columns", None)
+        if not enabled or filt is None:
+            return
+        lab = self.ymask != 0
+        if self.world == 1:
+            self.at_dz = filt(self.at, lab)
+        elif self.dz_plan is not None:
+            plan = self.plan_bwd
+            flag = torch.cat([lab, self.dz_halo_labelled[:plan.n_halo]]) if plan.n_halo else lab
+            self.at_dz = filt(plan.csr, flag)
+
+    def loss_gradient_nnz(self):
+        """Nonzeros of the local part of A^T that the product A^T dZ multiplies."""
+        if self.at_dz is not None:
+            return int(self.at_dz.nnz)
+        return int((self.plan_bwd.csr if self.world > 1 else self.at).nnz)
+
     def _aggregate_loss_gradient(self):
         """dP2 = A^T [dZ; halo rows of dZ] with only the labelled halo rows fetched."""
         sub, plan = self.dz_plan, self.plan_bwd
@@ -266,7 +299,8 @@ class FullBatchGCN(object):
             work.wait()
         if sub.n_halo:
             self.k.scatter_rows(sub.recv_buf[:sub.n_halo], sub.halo_pos, self.dz_halo)
-        self.k.spmm(plan.csr, self.dz, out=self.dp2, b2=self.dz_halo[:plan.n_halo] if plan.n_halo else None)
+        self.k.spmm(self.at_dz if self.at_dz is not None else plan.csr, self.dz, out=self.dp2,
+                    b2=self.dz_halo[:plan.n_halo] if plan.n_halo else None)
 
     def _exchange_rows(self, plan, src, dst):
         """dst[i, :] = row plan.need[i] of the global matrix whose local rows are
@@ -456,6 +490,8 @@ class FullBatchGCN(object):
         # layer 2
         if self.dz_plan is not None:
             self._aggregate_loss_gradient()                                  # A^T dZ, labelled halo rows only
+        elif self.at_dz is not None:
+            k.spmm(self.at_dz, self.dz, out=self.dp2)                        # A^T dZ, labelled columns only
         else:
             self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
         dp2_work = None
@@ -518,10 +554,13 @@ class FullBatchGCN(object):
         return 0.5 * self.wd * float((self.w1.double() ** 2).sum().item())
 
     # work accounting for the benchmark -------------------------------------
-    def spmm_units_per_step(self, nnz_global):
+    def spmm_units_per_step(self, nnz_global, nnz_loss_gradient_global=None):
         """nnz x width summed over the SpMM launches of one training step (four
         in the reference order; the aggregate-first order has no hidden-width
-        backward SpMM)."""
+        backward SpMM).  ``nnz_loss_gradient_global``: the nonzeros the product
+        A^T dZ actually multiplies, summed over the ranks (loss_gradient_nnz();
+        default: all of them)."""
+        nz = nnz_global if nnz_loss_gradient_global is None else nnz_loss_gradient_global
         if self.order == "aggregate_first":
-            return nnz_global * (self.f + 2 * self.c)
-        return nnz_global * (2 * self.h + 2 * self.c)
+            return nnz_global * (self.f + self.c) + nz * self.c
+        return nnz_global * (2 * self.h + self.c) + nz * self.c

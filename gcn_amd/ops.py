@@ -574,6 +574,12 @@ def scatter_rows(src, idx, out):
     return out
 
 
+def csr_filter_columns(a, col_keep):
+    """The sub-matrix of ``a`` (a Csr) with the nonzeros of the flagged columns only
+    (Csr.filter_columns): for products whose operand is exactly zero in the other rows."""
+    return a.filter_columns(col_keep)
+
+
 def philox_uniform(shape, lo, hi, seed, offset, device):
     """fp32 tensor of U(lo, hi) values, element i a pure function of
     (seed, offset + i) (synthetic benchmark inputs)."""

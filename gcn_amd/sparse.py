@@ -142,6 +142,36 @@ class Csr(object):
         self.gather_keep = None
         self._struct.gather_keep = None
 
+    # -------------------------------------------------------------- sub-matrix
+    def filter_columns(self, col_keep):
+        """The sub-matrix of the nonzeros whose column is flagged (``col_keep``: a
+        uint8 / bool tensor with one entry per column), same shape, kept nonzeros in
+        their order (gcnx_csr_filter_columns_count / _fill).  ``A.filter_columns(f) @ B``
+        equals ``A @ B`` when the rows of ``B`` outside ``f`` are exactly zero."""
+        lib = _lib.load()
+        flag = col_keep
+        if flag.dtype == torch.bool:
+            flag = flag.to(torch.uint8)
+        if flag.dtype != torch.uint8 or flag.dim() != 1 or flag.numel() != self.n_cols or flag.device != self.device:
+            raise ValueError("col_keep must be a uint8 or bool vector with one entry per column, on the matrix's device")
+        flag = flag.contiguous()
+        dev = self.device
+        row_ptr = torch.empty(self.n_rows + 1, dtype=torch.int64, device=dev)
+        kept = C.c_int64(0)
+        with torch.cuda.device(dev):
+            ws = torch.empty(max(lib.gcnx_csr_filter_workspace_bytes(self.nnz), 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gcnx_csr_filter_columns_count(self.struct_ref(), _ptr(flag), _ptr(row_ptr), C.byref(kept),
+                                                         _ptr(ws), ws.numel(), _stream()))
+            n = int(kept.value)
+            col = torch.empty(n, dtype=torch.int32, device=dev)
+            val = torch.empty(n, dtype=torch.float32, device=dev)
+            src = torch.empty(n, dtype=torch.int64, device=dev)
+            _lib.check(lib.gcnx_csr_filter_columns_fill(self.struct_ref(), _ptr(ws), ws.numel(), n, _ptr(col),
+                                                        _ptr(val), _ptr(src), _stream()))
+        idx = self.input_index[src] if self.input_index is not None else None
+        del ws
+        return Csr(self.n_rows, self.n_cols, row_ptr, col, val, idx)
+
     # ---------------------------------------------------------------- builders
     @classmethod
     def from_coo(cls, rows, cols, vals, shape, device="cuda", coords=None):

@@ -277,6 +277,21 @@ int gcnx_csr_gather_keep(const gcnx_csr *a, const int32_t *degree, int32_t min_d
 int gcnx_scatter_rows_f32(int64_t n_idx, const int32_t *idx, const float *src,
                           int64_t lds, int32_t width, float *dst, int64_t ldd,
                           void *stream);
+/* Sub-matrix of the nonzeros whose column is flagged (col_keep[j] != 0, one byte
+ * per column), same shape, kept nonzeros in their order.  For a product whose
+ * dense operand has rows known to be exactly zero: the gradient of the masked
+ * loss (gcn/metrics.py:4-11, mask / mean(mask) multiplies the per-row loss) is
+ * zero outside the labelled rows, so A_hat^T dZ only meets the labelled columns
+ * (the reference multiplies the zeros, tf.gradients of gcn/layers.py:222-226).
+ * Two calls around the caller's allocation: _count fills out_row_ptr
+ * [n_rows + 1] and *h_nnz (host; synchronises the stream), _fill writes the
+ * out_nnz = *h_nnz kept entries (out_src[k], optional: the slot of entry k in a)
+ * from the workspace _count left behind, which must not be touched in between. */
+size_t gcnx_csr_filter_workspace_bytes(int64_t nnz);
+int gcnx_csr_filter_columns_count(const gcnx_csr *a, const uint8_t *col_keep, int64_t *out_row_ptr,
+                                  int64_t *h_nnz, void *ws, size_t ws_bytes, void *stream);
+int gcnx_csr_filter_columns_fill(const gcnx_csr *a, const void *ws, size_t ws_bytes, int64_t out_nnz,
+                                 int32_t *out_col, float *out_val, int64_t *out_src, void *stream);
 
 /* ---- the exchange itself, over RCCL (xGMI inside a node) ------------------
  * No counterpart in the reference (single process).  One process per GPU; every

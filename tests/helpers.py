@@ -82,6 +82,19 @@ class OracleKernels(object):
         out.n_cols = int(n_loc + len(need))
         return out, self.torch.from_numpy(need.astype(np.int32))
 
+    def csr_filter_columns(self, a, col_keep):
+        """numpy counterpart of gcn_amd.sparse.Csr.filter_columns."""
+        import copy
+        flag = np.asarray(col_keep.numpy() if hasattr(col_keep, "numpy") else col_keep) != 0
+        keep = flag[a.col_idx.astype(np.int64)]
+        before = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+        out = copy.copy(a)
+        out.row_ptr = before[a.row_ptr].astype(np.int64)
+        out.col_idx = a.col_idx[keep]
+        out.val = a.val[keep]
+        out.nnz = int(keep.sum())
+        return out
+
     def gather_rows(self, src, idx, out):
         out.copy_(src[idx.long()])
         return out

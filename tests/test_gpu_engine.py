@@ -66,7 +66,9 @@ def _dense_tuple(x):
     (256, 16, "reference", 11, 128),
     # (A_hat X') W1: the same sums associated the other way (the oracle keeps the
     # reference order); the second case runs the fused relu + dropout epilogue
-    (16, 7, "aggregate_first", 9, 48), (128, 16, "aggregate_first", 11, 64)])
+    (16, 7, "aggregate_first", 9, 48), (128, 16, "aggregate_first", 11, 64),
+    # A_hat^T dZ over every nonzero (the default restricts it to the labelled columns)
+    (128, 16, "reference-dense-dz", 9, 48)])
 def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
@@ -79,8 +81,16 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
     lmask = (rng.random_sample(n) < 0.2).astype(np.uint8)
     T = lambda v: torch.from_numpy(v).to(dev)
+    sparse_dz = order != "reference-dense-dz"
+    order = order.split("-")[0]
     eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
-                                     T(w1), T(w2), seed=123, order=order)
+                                     T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz)
+    if sparse_dz:
+        # the product A_hat^T dZ runs over the nonzeros of the labelled columns only
+        want_nnz = int(lmask[a.col_idx.cpu().numpy()].sum())
+        assert eng.at_dz is not None and eng.at_dz.nnz == want_nnz == eng.loss_gradient_nnz() < a.nnz
+    else:
+        assert eng.at_dz is None and eng.loss_gradient_nnz() == a.nnz
     rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
     sup = (np.stack([rows, ci], 1), v, (n, n))

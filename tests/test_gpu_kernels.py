@@ -749,6 +749,45 @@ def test_degenerate_sizes_are_no_ops(env):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,n_cols,nnz,frac", [(300, 260, 5000, 0.3), (64, 64, 64 * 64, 0.5), (1000, 1000, 64 * 7, 0.01),
+                                               (50, 40, 777, 1.0), (50, 40, 777, 0.0), (10, 10, 0, 0.5),
+                                               (5000, 4000, 200001, 0.1)])
+def test_filter_columns_keeps_flagged_nonzeros_in_order(env, n, n_cols, nnz, frac):
+    """gcnx_csr_filter_columns_count / _fill against numpy: row pointers, kept entries
+    and their source slots; hub and empty rows; all / no columns flagged; nnz a
+    multiple of 64 and zero.  And the product with an operand that is zero outside the
+    flagged rows does not change."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(n + nnz)
+    if nnz:
+        rows, cols, vals = random_coo(rng, n, n_cols, nnz, hub_rows=((3, nnz // 4),), empty_rows=(0, n - 1))
+    else:
+        rows = cols = np.zeros(0, dtype=np.int32)
+        vals = np.zeros(0)
+    a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n_cols), device=dev)
+    flag = (rng.random_sample(n_cols) < frac) if 0.0 < frac < 1.0 else np.full(n_cols, frac >= 1.0)
+    sub = a.filter_columns(torch.from_numpy(flag).to(dev))
+    rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
+    keep = flag[ci]
+    before = np.concatenate([[0], np.cumsum(keep, dtype=np.int64)])
+    assert sub.shape == a.shape and sub.nnz == int(keep.sum())
+    assert np.array_equal(sub.row_ptr.cpu().numpy(), before[rp])
+    assert np.array_equal(sub.col_idx.cpu().numpy(), ci[keep])
+    assert np.array_equal(sub.val.cpu().numpy(), v[keep])
+    assert np.array_equal(sub.input_index.cpu().numpy(), a.input_index.cpu().numpy()[keep])
+    b = rng.standard_normal((n_cols, 16)).astype(np.float32)
+    b[~flag] = 0.0
+    bt = torch.from_numpy(b).to(dev)
+    full, part = ops.spmm(a, bt), ops.spmm(sub, bt)
+    assert float((full - part).abs().max()) <= 1e-6 * float(full.abs().max()) + 1e-30
+    # a uint8 flag vector is taken as it is; a wrong length is refused before any launch
+    sub2 = a.filter_columns(torch.from_numpy(flag.astype(np.uint8)).to(dev))
+    assert sub2.nnz == sub.nnz and torch.equal(sub2.col_idx, sub.col_idx)
+    with pytest.raises(ValueError):
+        a.filter_columns(torch.zeros(n_cols + 1, dtype=torch.uint8, device=dev))
+
+
 @pytest.fixture(params=["split_bf16", "f32_chain"])
 def dense_arith(request, env):
     """Both arithmetic modes of the large dense products: exactly split operands
