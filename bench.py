@@ -245,11 +245,11 @@ def main():
                        row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
                        slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
                        sparse_loss_gradient=not args.dense_loss_gradient)
-    nnz_dz = torch.tensor([model.loss_gradient_nnz()], dtype=torch.int64,
+    nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
                           device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(nnz_dz, group=group)
-    nnz_dz_global = int(nnz_dz.item())
+    nnz_dz_global, nnz_bwd_global = (int(v) for v in nnz_dz.tolist())
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -327,7 +327,7 @@ def main():
 
     if rank == 0:
         # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
-        units = model.spmm_units_per_step(nnz_global, nnz_dz_global)
+        units = model.spmm_units_per_step(nnz_global, nnz_dz_global, nnz_bwd_global)
         result = {
             "metric": "GCN SpMM nnz*F/s (full-batch epoch: fwd + bwd + Adam)",
             "value": units * args.steps / dt,
@@ -346,14 +346,16 @@ def main():
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
                              if comm is not None else "torch.distributed " + args.backend),
                 "order": args.order, "dense_arith": args.dense_arith,
-                "nnz_loss_gradient_product": nnz_dz_global,
+                "nnz_loss_gradient_product": nnz_dz_global, "nnz_backward_product": nnz_bwd_global,
                 "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),
                 "spmm_per_step": (("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
                                    if args.order == "reference" else
                                    "1 x width %d + 2 x width %d" % (args.features, args.classes)) +
                                   ("" if nnz_dz_global == nnz_global else
-                                   "; A_hat^T dZ over the %d nonzeros of the labelled columns (dZ is zero elsewhere), "
-                                   "counted as such in value" % nnz_dz_global)),
+                                   "; A_hat^T dZ over the %d nonzeros of the labelled columns and A_hat^T d(A P1) "
+                                   "over the %d nonzeros of the columns with a labelled neighbour (the gradients "
+                                   "are exactly zero elsewhere), counted as such in value"
+                                   % (nnz_dz_global, nnz_bwd_global))),
             },
             "epoch_ms": dt / args.steps * 1e3,
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],

@@ -75,10 +75,12 @@ class FullBatchGCN(object):
         set-up exchanges of the halo plan always use ``group``.
         ``sparse_loss_gradient``: the rows of dZ outside the labelled set are
         exactly zero (the mask multiplies the per-row loss, gcn/metrics.py:4-11), so
-        A_hat^T dZ is formed with the nonzeros of the labelled columns only -- a
-        sub-matrix built once, the label mask being fixed; every row of dP2 is
-        still written and no sum changes (False: the full matrix, zeros
-        multiplied as the reference does)."""
+        A_hat^T dZ is formed with the nonzeros of the labelled columns only, and
+        A_hat^T d(A P1) with the nonzeros of the columns that have a labelled
+        neighbour (the other rows of dP2, hence of d(A P1), are exactly zero) --
+        sub-matrices built once, the label mask being fixed; every row of every
+        gradient is still written and no sum changes (False: the full matrix,
+        zeros multiplied as the reference does)."""
         self.k = kernels if kernels is not None else _hip_ops
         self.comm = comm
         self.a = a_local
@@ -159,6 +161,7 @@ class FullBatchGCN(object):
             self.recompute = False
             self.dz_plan = None
         self._setup_loss_gradient_matrix(sparse_loss_gradient)
+        self._setup_backward_matrix()
         # the hidden-width forward product gathers 4 h bytes per nonzero from an operand
         # far larger than the caches: tell the kernel which rows are worth keeping there
         self._hint_forward_matrix()
@@ -284,6 +287,37 @@ class FullBatchGCN(object):
             plan = self.plan_bwd
             flag = torch.cat([lab, self.dz_halo_labelled[:plan.n_halo]]) if plan.n_halo else lab
             self.at_dz = filt(plan.csr, flag)
+
+    def _setup_backward_matrix(self):
+        """``self.at_wide``: the matrix of the hidden-width backward product
+        A^T d(A P1) restricted to the columns whose row of d(A P1) can be nonzero.
+        d(A P1) = gate(dP2 W2^T) row by row, and a row of dP2 = A^T dZ is exactly
+        zero unless the node has a labelled neighbour (or is labelled): the rows of
+        ``self.at_dz`` that hold a nonzero.  None: the full matrix."""
+        self.at_wide = None
+        filt = getattr(self.k, "csr_filter_columns", None)
+        if self.at_dz is None or filt is None or self.order == "aggregate_first":
+            return
+        rp = torch.as_tensor(self.at_dz.row_ptr)
+        hit = (rp[1:] - rp[:-1]) > 0                     # local rows of dP2 that can be nonzero
+        if self.world == 1:
+            self.at_wide = filt(self.at, hit)
+        elif self.recompute:
+            plan = self.plan
+            flag = hit
+            if plan.n_halo:
+                # the owners tell which of the requested rows can be nonzero (set-up, once)
+                col = hit.to(torch.float32).view(-1, 1).contiguous().to(self.dev)
+                got = torch.zeros((plan.n_halo, 1), dtype=torch.float32, device=self.dev)
+                self._exchange_rows(plan, col, got)
+                flag = torch.cat([hit.to(got.device), got[:, 0] != 0])
+            self.at_wide = filt(plan.csr, flag)
+
+    def backward_nnz(self):
+        """Nonzeros of the local part of A^T that the hidden-width backward product multiplies."""
+        if self.at_wide is not None:
+            return int(self.at_wide.nnz)
+        return int((self.plan_bwd.csr if self.world > 1 else self.at).nnz)
 
     def loss_gradient_nnz(self):
         """Nonzeros of the local part of A^T that the product A^T dZ multiplies."""
@@ -520,7 +554,8 @@ class FullBatchGCN(object):
             self._bits_work = None
             if self.factored_bwd:
                 # local and halo rows of d(A P1) alike from dP2 rows and sign words
-                k.spmm_factored(plan.csr, self.dp2, self.w2, self.hbits, gate_scale=1.0 / keep, trans_w=True,
+                k.spmm_factored(self.at_wide if self.at_wide is not None else plan.csr, self.dp2, self.w2,
+                                self.hbits, gate_scale=1.0 / keep, trans_w=True,
                                 out=self.hb, d2=self.dp2_halo[:nh] if nh else None,
                                 gate_bits2=self.hbits_halo[:nh] if nh else None)
             else:
@@ -529,10 +564,13 @@ class FullBatchGCN(object):
                     # of dP2 and the received sign bits of the owners' H'
                     k.gemm(self.dp2_halo[:nh], self.w2, trans_b=True, out=self.wide_halo[:nh],
                            gate_bits=self.hbits_halo[:nh], gate_scale=1.0 / keep)
-                k.spmm(plan.csr, self.p1, out=self.hb, b2=self.wide_halo[:nh] if nh else None)
+                k.spmm(self.at_wide if self.at_wide is not None else plan.csr, self.p1, out=self.hb,
+                       b2=self.wide_halo[:nh] if nh else None)
         elif self.factored_bwd:
-            k.spmm_factored(self.at, self.dp2, self.w2, self.hbits, gate_scale=1.0 / keep, trans_w=True,
-                            out=self.hb)                                    # A^T dH -> dP1, dH never stored
+            k.spmm_factored(self.at_wide if self.at_wide is not None else self.at, self.dp2, self.w2, self.hbits,
+                            gate_scale=1.0 / keep, trans_w=True, out=self.hb)   # A^T dH -> dP1, dH never stored
+        elif self.world == 1 and self.at_wide is not None:
+            k.spmm(self.at_wide, self.p1, out=self.hb)                   # A^T dH -> dP1
         else:
             self._aggregate("bwd", self.p1, self.hb, relu=False)         # A^T dH -> dP1
         if self.order != "aggregate_first":
@@ -554,13 +592,14 @@ class FullBatchGCN(object):
         return 0.5 * self.wd * float((self.w1.double() ** 2).sum().item())
 
     # work accounting for the benchmark -------------------------------------
-    def spmm_units_per_step(self, nnz_global, nnz_loss_gradient_global=None):
+    def spmm_units_per_step(self, nnz_global, nnz_loss_gradient_global=None, nnz_backward_global=None):
         """nnz x width summed over the SpMM launches of one training step (four
         in the reference order; the aggregate-first order has no hidden-width
-        backward SpMM).  ``nnz_loss_gradient_global``: the nonzeros the product
-        A^T dZ actually multiplies, summed over the ranks (loss_gradient_nnz();
-        default: all of them)."""
+        backward SpMM).  ``nnz_loss_gradient_global`` / ``nnz_backward_global``:
+        the nonzeros the products A^T dZ and A^T d(A P1) actually multiply, summed
+        over the ranks (loss_gradient_nnz(), backward_nnz(); default: all of them)."""
         nz = nnz_global if nnz_loss_gradient_global is None else nnz_loss_gradient_global
+        nb = nnz_global if nnz_backward_global is None else nnz_backward_global
         if self.order == "aggregate_first":
             return nnz_global * (self.f + self.c) + nz * self.c
-        return nnz_global * (2 * self.h + self.c) + nz * self.c
+        return nnz_global * (self.h + self.c) + nb * self.h + nz * self.c

@@ -89,8 +89,15 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
         # the product A_hat^T dZ runs over the nonzeros of the labelled columns only
         want_nnz = int(lmask[a.col_idx.cpu().numpy()].sum())
         assert eng.at_dz is not None and eng.at_dz.nnz == want_nnz == eng.loss_gradient_nnz() < a.nnz
+        if order == "reference":
+            # ... and A_hat^T d(A P1) over the columns with a labelled neighbour: the rows
+            # of dP2 = A_hat^T dZ that can be nonzero
+            rp_h, ci_h = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy()
+            touched = np.add.reduceat(np.append(lmask[ci_h].astype(np.int64), 0), rp_h[:-1]) * (np.diff(rp_h) > 0) > 0
+            assert eng.at_wide is not None and eng.at_wide.nnz == int(touched[ci_h].sum()) == eng.backward_nnz()
     else:
-        assert eng.at_dz is None and eng.loss_gradient_nnz() == a.nnz
+        assert eng.at_dz is None and eng.at_wide is None
+        assert eng.loss_gradient_nnz() == a.nnz == eng.backward_nnz()
     rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
     sup = (np.stack([rows, ci], 1), v, (n, n))
