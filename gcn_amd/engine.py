@@ -276,7 +276,7 @@ class FullBatchGCN(object):
         """``self.at_dz``: the matrix of the product A^T dZ restricted to the columns
         whose dZ row can be nonzero (labelled local rows and labelled halo rows), or
         None (the full matrix is used)."""
-        self.at_dz = None
+        self.at_dz = self.at_dz_c = self.dz_rows = None
         filt = getattr(self.k, "csr_filter_columns", None)
         if not enabled or filt is None:
             return
@@ -287,6 +287,18 @@ class FullBatchGCN(object):
             plan = self.plan_bwd
             flag = torch.cat([lab, self.dz_halo_labelled[:plan.n_halo]]) if plan.n_halo else lab
             self.at_dz = filt(plan.csr, flag)
+        # Few rows of dP2 can be nonzero (the nodes with a labelled neighbour): the
+        # product writes them next to each other and they are put in place in the
+        # resident dP2, whose other rows stay zero; H'^T dP2 sums over those rows only
+        compact = getattr(self.k, "csr_compact_rows", None)
+        if self.at_dz is not None and compact is not None and hasattr(self.k, "scatter_rows") and \
+                hasattr(self.k, "gather_rows"):
+            sub, rows = compact(self.at_dz)
+            if 0 < sub.n_rows <= self.n_loc // 2:
+                self.at_dz_c, self.dz_rows = sub, rows.to(self.dev)
+                self.dp2_c = torch.empty((sub.n_rows, self.c), dtype=torch.float32, device=self.dev)
+                self.hd_c = torch.empty((sub.n_rows, self.h), dtype=torch.float32, device=self.dev)
+                self.dp2.zero_()
 
     def _setup_backward_matrix(self):
         """``self.at_wide``: the matrix of the hidden-width backward product
@@ -325,6 +337,15 @@ class FullBatchGCN(object):
             return int(self.at_dz.nnz)
         return int((self.plan_bwd.csr if self.world > 1 else self.at).nnz)
 
+    def _loss_gradient_product(self, b2=None):
+        """dP2 = A^T [dZ; b2] through the sub-matrix of the labelled columns, its
+        nonzero rows formed next to each other and put in place when that pays."""
+        if self.at_dz_c is not None:
+            self.k.spmm(self.at_dz_c, self.dz, out=self.dp2_c, b2=b2)
+            self.k.scatter_rows(self.dp2_c, self.dz_rows, self.dp2)
+        else:
+            self.k.spmm(self.at_dz, self.dz, out=self.dp2, b2=b2)
+
     def _aggregate_loss_gradient(self):
         """dP2 = A^T [dZ; halo rows of dZ] with only the labelled halo rows fetched."""
         sub, plan = self.dz_plan, self.plan_bwd
@@ -333,8 +354,11 @@ class FullBatchGCN(object):
             work.wait()
         if sub.n_halo:
             self.k.scatter_rows(sub.recv_buf[:sub.n_halo], sub.halo_pos, self.dz_halo)
-        self.k.spmm(self.at_dz if self.at_dz is not None else plan.csr, self.dz, out=self.dp2,
-                    b2=self.dz_halo[:plan.n_halo] if plan.n_halo else None)
+        b2 = self.dz_halo[:plan.n_halo] if plan.n_halo else None
+        if self.at_dz is not None:
+            self._loss_gradient_product(b2)
+        else:
+            self.k.spmm(plan.csr, self.dz, out=self.dp2, b2=b2)
 
     def _exchange_rows(self, plan, src, dst):
         """dst[i, :] = row plan.need[i] of the global matrix whose local rows are
@@ -525,7 +549,7 @@ class FullBatchGCN(object):
         if self.dz_plan is not None:
             self._aggregate_loss_gradient()                                  # A^T dZ, labelled halo rows only
         elif self.at_dz is not None:
-            k.spmm(self.at_dz, self.dz, out=self.dp2)                        # A^T dZ, labelled columns only
+            self._loss_gradient_product()                                    # A^T dZ, labelled columns only
         else:
             self._aggregate("bwd", self.dz, self.dp2, relu=False)            # A^T dZ
         dp2_work = None
@@ -533,7 +557,12 @@ class FullBatchGCN(object):
             plan = self.plan
             dp2_work = self._exchange_start(plan, self.dp2, 0, self.c, self.dp2_send[:plan.n_send],
                                             self.dp2_halo[:plan.n_halo])
-        k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                    # H'^T dP2
+        if self.at_dz_c is not None:
+            # the rows of dP2 that can be nonzero, and the same rows of H'
+            k.gather_rows(hin, self.dz_rows, self.hd_c)
+            k.gemm(self.hd_c, self.dp2_c, trans_a=True, out=self.g2)       # H'^T dP2
+        else:
+            k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
         if self.factored_bwd:
             pass                            # formed per nonzero inside the SpMM below

@@ -580,6 +580,12 @@ def csr_filter_columns(a, col_keep):
     return a.filter_columns(col_keep)
 
 
+def csr_compact_rows(a):
+    """``(sub, rows)``: ``a`` without its empty rows and the int32 ids of the rows kept
+    (Csr.compact_rows)."""
+    return a.compact_rows()
+
+
 def philox_uniform(shape, lo, hi, seed, offset, device):
     """fp32 tensor of U(lo, hi) values, element i a pure function of
     (seed, offset + i) (synthetic benchmark inputs)."""

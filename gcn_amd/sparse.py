@@ -172,6 +172,17 @@ class Csr(object):
         del ws
         return Csr(self.n_rows, self.n_cols, row_ptr, col, val, idx)
 
+    def compact_rows(self):
+        """``(sub, rows)``: the matrix without its empty rows (``sub`` shares the
+        column and value arrays; row i of ``sub`` is row ``rows[i]`` of this matrix,
+        ``rows`` int32 ascending).  A product with ``sub`` writes the rows that can be
+        nonzero next to each other; gcnx_scatter_rows_f32 puts them in place."""
+        deg = self.row_ptr[1:] - self.row_ptr[:-1]
+        rows = torch.nonzero(deg > 0).view(-1)
+        row_ptr = torch.cat([self.row_ptr[rows], self.row_ptr[-1:]]).contiguous()
+        sub = Csr(int(rows.numel()), self.n_cols, row_ptr, self.col_idx, self.val, self.input_index)
+        return sub, rows.to(torch.int32).contiguous()
+
     # ---------------------------------------------------------------- builders
     @classmethod
     def from_coo(cls, rows, cols, vals, shape, device="cuda", coords=None):

@@ -95,6 +95,15 @@ class OracleKernels(object):
         out.nnz = int(keep.sum())
         return out
 
+    def csr_compact_rows(self, a):
+        """numpy counterpart of gcn_amd.sparse.Csr.compact_rows."""
+        import copy
+        rows = np.nonzero(np.diff(a.row_ptr) > 0)[0]
+        out = copy.copy(a)
+        out.row_ptr = np.concatenate([a.row_ptr[rows], a.row_ptr[-1:]]).astype(np.int64)
+        out.n_rows = int(len(rows))
+        return out, self.torch.from_numpy(rows.astype(np.int32))
+
     def gather_rows(self, src, idx, out):
         out.copy_(src[idx.long()])
         return out

@@ -68,7 +68,10 @@ def _dense_tuple(x):
     # reference order); the second case runs the fused relu + dropout epilogue
     (16, 7, "aggregate_first", 9, 48), (128, 16, "aggregate_first", 11, 64),
     # A_hat^T dZ over every nonzero (the default restricts it to the labelled columns)
-    (128, 16, "reference-dense-dz", 9, 48)])
+    (128, 16, "reference-dense-dz", 9, 48),
+    # few labelled nodes: the rows of dP2 that can be nonzero are formed next to each
+    # other and H'^T dP2 sums over those rows only
+    (256, 16, "reference-few-labels", 11, 128), (16, 7, "reference-few-labels", 10, 48)])
 def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
@@ -79,9 +82,10 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     w1 = (rng.uniform(-1, 1, (f, hidden)) * 0.2).astype(np.float32)
     w2 = (rng.uniform(-1, 1, (hidden, classes)) * 0.2).astype(np.float32)
     labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
-    lmask = (rng.random_sample(n) < 0.2).astype(np.uint8)
+    lmask = (rng.random_sample(n) < (0.01 if order.endswith("few-labels") else 0.2)).astype(np.uint8)
     T = lambda v: torch.from_numpy(v).to(dev)
     sparse_dz = order != "reference-dense-dz"
+    few = order.endswith("few-labels")
     order = order.split("-")[0]
     eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
                                      T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz)
@@ -89,12 +93,16 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
         # the product A_hat^T dZ runs over the nonzeros of the labelled columns only
         want_nnz = int(lmask[a.col_idx.cpu().numpy()].sum())
         assert eng.at_dz is not None and eng.at_dz.nnz == want_nnz == eng.loss_gradient_nnz() < a.nnz
+        # the rows of dP2 = A_hat^T dZ that can be nonzero: the nodes with a labelled neighbour
+        rp_h, ci_h = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy()
+        touched = np.add.reduceat(np.append(lmask[ci_h].astype(np.int64), 0), rp_h[:-1]) * (np.diff(rp_h) > 0) > 0
         if order == "reference":
-            # ... and A_hat^T d(A P1) over the columns with a labelled neighbour: the rows
-            # of dP2 = A_hat^T dZ that can be nonzero
-            rp_h, ci_h = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy()
-            touched = np.add.reduceat(np.append(lmask[ci_h].astype(np.int64), 0), rp_h[:-1]) * (np.diff(rp_h) > 0) > 0
+            # ... and A_hat^T d(A P1) runs over the nonzeros of those columns
             assert eng.at_wide is not None and eng.at_wide.nnz == int(touched[ci_h].sum()) == eng.backward_nnz()
+        if few:
+            assert eng.at_dz_c is not None
+        if eng.at_dz_c is not None:
+            assert np.array_equal(eng.dz_rows.cpu().numpy(), np.nonzero(touched)[0])
     else:
         assert eng.at_dz is None and eng.at_wide is None
         assert eng.loss_gradient_nnz() == a.nnz == eng.backward_nnz()
