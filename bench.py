@@ -284,14 +284,17 @@ def main():
         def gemm(self, x, y, **kw):
             # the two 2*N*F*hidden-flop products of the step (X' W1 and X'^T dP1)
             # get an event pair each (they run on torch's current stream)
-            big = x.shape[0] == n_loc and x.shape[1] == args.features and y.shape[-1] == args.hidden and \
-                (bool(kw.get("trans_a")) == (y.shape[0] == n_loc))
+            # (the second one sums over the rows of dP1 that can be nonzero: x then holds those rows)
+            ta = bool(kw.get("trans_a"))
+            big = x.shape[1] == args.features and y.shape[-1] == args.hidden and \
+                ((not ta and x.shape[0] == n_loc and y.shape[0] == args.features) or
+                 (ta and y.shape[0] == x.shape[0] and x.shape[0] >= n_loc // 8))
             if Timed.armed and big and args.order == "reference" and len(gemm_ev) < n_ev:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 out = ops.gemm(x, y, **kw)
                 e.record()
-                gemm_ev.append((s, e, "tn" if kw.get("trans_a") else "nn"))
+                gemm_ev.append((s, e, "tn" if ta else "nn", int(x.shape[0])))
                 return out
             return ops.gemm(x, y, **kw)
 
@@ -391,12 +394,14 @@ def main():
                 "compulsory_bytes_per_launch": 8 * a.nnz + 8 * a.n_rows * args.hidden + 8 * (a.n_rows + 1),
             }
         if gemm_ev:
-            flops = 2.0 * n_loc * args.features * args.hidden
             split = ops.dense_arith() == 0
             dense_peak = MFMA_BF16_PEAK / SPLIT_PARTIAL_PRODUCTS if split else MFMA_F32_PEAK
-            per = {}
-            for s_, e_, kind in gemm_ev:
+            per, rows_summed = {}, {}
+            for s_, e_, kind, k_rows in gemm_ev:
                 per.setdefault(kind, []).append(s_.elapsed_time(e_) * 1e-3)
+                rows_summed[kind] = k_rows
+            # flops of the products as launched (the weight gradient over the rows it sums)
+            flops_of = {kind: 2.0 * rows_summed[kind] * args.features * args.hidden for kind in per}
             result["roofline_dense"] = {
                 kind: {"bound": "mfma",
                        "kernel": (("gemm_split_nn_kernel" if split else "gemm_mfma_kernel<256>") + " (dropout(X) W1)"
@@ -406,11 +411,12 @@ def main():
                        "arith": ("fp32 operands split exactly into 3 bf16 pieces, 6 partial products per product on "
                                  "v_mfma_f32_32x32x16_bf16, fp32 accumulate (fp32 accuracy)" if split else
                                  "v_mfma_f32_32x32x2_f32 chains (exact fp32)"),
-                       "achieved": flops / (sum(v) / len(v)) / 1e12, "peak": dense_peak / 1e12,
+                       "achieved": flops_of[kind] / (sum(v) / len(v)) / 1e12, "peak": dense_peak / 1e12,
                        "peak_is": ("dense bf16 MFMA peak / 6 partial products" if split else "dense fp32 MFMA peak"),
                        "fp32_mfma_peak": MFMA_F32_PEAK / 1e12,
-                       "unit": "TFLOP/s (fp32-product flops)", "frac": flops / (sum(v) / len(v)) / dense_peak,
-                       "flops_per_launch": flops, "avg_launch_ms": sum(v) / len(v) * 1e3, "launches_timed": len(v)}
+                       "unit": "TFLOP/s (fp32-product flops)", "frac": flops_of[kind] / (sum(v) / len(v)) / dense_peak,
+                       "flops_per_launch": flops_of[kind], "rows_summed_or_formed": rows_summed[kind],
+                       "avg_launch_ms": sum(v) / len(v) * 1e3, "launches_timed": len(v)}
                 for kind, v in per.items()}
         if args.cpu_rows and world == 1:
             try:

@@ -92,6 +92,9 @@ SIGNATURES = {
     "gcnx_pack_sign_bits_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),
     "gcnx_gemm_dropout_a_rows_f32": (_int, [_int, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64,
                                             _f32, _f32, _p, _sz, _p]),
+    "gcnx_gemm_dropout_at_rows_supported": (_int, [_i64, _i64, _i64]),
+    "gcnx_gemm_dropout_at_rows_f32": (_int, [_i64, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64,
+                                             _f32, _f32, _p, _sz, _p]),
     "gcnx_halo_plan_workspace_bytes": (_sz, [_i64]),
     "gcnx_halo_plan": (_int, [_csr_p, _i64, _i64, _p, _p, _i64, C.POINTER(_i64), _p, _sz, _p]),
     "gcnx_gather_rows_f32": (_int, [_i64, _p, _p, _i64, _i32, _p, _i64, _p]),

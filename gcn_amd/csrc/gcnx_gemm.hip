@@ -829,8 +829,13 @@ __device__ __forceinline__ bf8v tr_frag(const unsigned char *p, int row_pitch) {
   return __builtin_bit_cast(bf8v, v);
 }
 
-template <bool DROP>   // the Philox dropout of A compiled in or out
+// ROWS: row k of A draws the dropout mask of row g.adrop_rows[k] (A holds a gathered
+// subset of the rows the mask is defined on); the ids travel two K steps ahead of
+// the draw that needs them, next to the tile loads, so that no wait for them falls
+// between the loads and the MFMAs.
+template <bool DROP, bool ROWS = false>   // the Philox dropout of A compiled in or out
 __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs g) {
+  static_assert(DROP || !ROWS, "row ids only select dropout masks");
   constexpr int BM = 128, BN = 256, BK = 16;
   constexpr int PA = BM * 2 + 64, PB = BN * 2 + 64;           // row pitches in bytes
   constexpr int kAPiece = BK * PA, kBPiece = BK * PB;
@@ -874,13 +879,22 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs
   // of indices only: it is drawn (Philox, ~150 vector instructions) in the shadow
   // of the previous step's MFMAs and kept as 8 bits.
   unsigned keep_bits = 0;
+  int rid_cur[2] = {0, 0}, rid_nxt[2] = {0, 0};    // ROWS: mask rows of the next draw / of the one after
+  auto load_rids = [&](int64_t kk, int (&dst)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t r = kk + ((tid + i * kBlock) >> 5);
+      dst[i] = r < kend ? g.adrop_rows[r] : 0;
+    }
+  };
   auto draw_keep = [&](int64_t kk) {
     keep_bits = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * kBlock;
       const int k = e >> 5, q = e & 31;
-      const uint64_t e0 = g.adrop_offset + (uint64_t)(kk + k) * (uint64_t)g.adrop_ld + (uint64_t)(m0 + q * 4);
+      const uint64_t mask_row = ROWS ? (uint64_t)(int64_t)rid_cur[i] : (uint64_t)(kk + k);
+      const uint64_t e0 = g.adrop_offset + mask_row * (uint64_t)g.adrop_ld + (uint64_t)(m0 + q * 4);
       const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, g.adrop_seed);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -924,12 +938,19 @@ __global__ __launch_bounds__(kBlock, 2) void gemm_split_tn_kernel(const GemmArgs
   const int b_tr = ((grp >> 1) * 8 + gq) * PB + ((wn * 4) * 32 + (grp & 1) * 16 + gp * 4) * 2;
   (void)li; (void)lk;
   if (kbeg < kend) load_tiles(kbeg);
+  if (ROWS && kbeg < kend) {
+    load_rids(kbeg, rid_cur);
+    load_rids(kbeg + BK, rid_nxt);
+  }
   if (DROP && kbeg < kend) draw_keep(kbeg);
+  if (ROWS) { rid_cur[0] = rid_nxt[0]; rid_cur[1] = rid_nxt[1]; }
   for (int64_t kk = kbeg; kk < kend; kk += BK) {
     store_tiles(kk);
     __syncthreads();
     if (kk + BK < kend) load_tiles(kk + BK);
+    if (ROWS) load_rids(kk + 2 * BK, rid_nxt);     // past the end: zeros, no load
     if (DROP) draw_keep(kk + BK);           // past the last step: drawn and not used (no branch in the MFMA block)
+    if (ROWS) { rid_cur[0] = rid_nxt[0]; rid_cur[1] = rid_nxt[1]; }
     bf8v af[2][3];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -1480,6 +1501,22 @@ extern "C" int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, i
                    a_dropout, a_row_ids, nullptr, 0, nullptr, ws, ws_bytes, stream);
 }
 
+extern "C" int gcnx_gemm_dropout_at_rows_supported(int64_t M, int64_t N, int64_t K) {
+  return (tn_mfma_shape(M, N, K) && M % 4 == 0 && N % 256 == 0 && dense_arith_mode() == 0) ? 1 : 0;
+}
+
+extern "C" int gcnx_gemm_dropout_at_rows_f32(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                                             const gcnx_dropout *a_dropout, const int32_t *a_row_ids,
+                                             const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
+                                             float beta, void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(a_dropout && a_row_ids, GCNX_ERR_INVALID_ARG, "gemm_dropout_at_rows: null argument");
+  GCNX_REQUIRE(a_dropout->keep < 1.0f, GCNX_ERR_INVALID_ARG, "gemm_dropout_at_rows: keep must be below 1");
+  GCNX_REQUIRE(gcnx_gemm_dropout_at_rows_supported(M, N, K), GCNX_ERR_UNSUPPORTED,
+               "gemm_dropout_at_rows: shape or arithmetic not served (gcnx_gemm_dropout_at_rows_supported)");
+  return gemm_impl(1, 0, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, 0, nullptr, 0, 1.0f, a_dropout,
+                   a_row_ids, nullptr, 0, nullptr, ws, ws_bytes, stream);
+}
+
 extern "C" int gcnx_gemm_gated_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                                    const float *A, int64_t lda, const float *B, int64_t ldb,
                                    float *C, int64_t ldc, float alpha, float beta,
@@ -1573,7 +1610,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
                  GCNX_ERR_INVALID_ARG, "gemm: A-dropout needs keep > 0, offset and ld multiples of 4, col0 = 0");
     g.adrop_keep = a_drop->keep; g.adrop_seed = a_drop->seed; g.adrop_offset = a_drop->offset;
     g.adrop_ld = a_drop->ld;
-    GCNX_REQUIRE(!a_rows || !trans_a, GCNX_ERR_UNSUPPORTED, "gemm: row ids for the A-dropout need a plain A");
+    // with a transposed A the row ids are served by the split-operand kernel only (checked at its dispatch)
     g.adrop_rows = a_rows;
   }
 
@@ -1709,9 +1746,15 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
       g.splits = sp;
       g.k_per_split = ceil_div(ceil_div(K, sp), 16) * 16;
     }
+    GCNX_REQUIRE(!g.adrop_rows || (N % 256 == 0 && dense_arith_mode() == 0 && g.adrop_keep < 1.0f),
+                 GCNX_ERR_UNSUPPORTED,
+                 "gemm: row ids for the dropout of a transposed A need N %% 256 == 0 and the split-operand arithmetic");
     if (N % 256 == 0 && dense_arith_mode() == 0) {
       // exactly split operands on the bf16 matrix pipe
-      if (g.adrop_keep < 1.0f)
+      if (g.adrop_keep < 1.0f && g.adrop_rows)
+        hipLaunchKernelGGL((gemm_split_tn_kernel<true, true>), dim3((unsigned)(M / 128), (unsigned)(N / 256),
+                           (unsigned)g.splits), dim3(kBlock), 0, st, g);
+      else if (g.adrop_keep < 1.0f)
         hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)(M / 128), (unsigned)(N / 256), (unsigned)g.splits),
                            dim3(kBlock), 0, st, g);
       else

@@ -306,7 +306,7 @@ class FullBatchGCN(object):
         d(A P1) = gate(dP2 W2^T) row by row, and a row of dP2 = A^T dZ is exactly
         zero unless the node has a labelled neighbour (or is labelled): the rows of
         ``self.at_dz`` that hold a nonzero.  None: the full matrix."""
-        self.at_wide = None
+        self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
         filt = getattr(self.k, "csr_filter_columns", None)
         if self.at_dz is None or filt is None or self.order == "aggregate_first":
             return
@@ -324,6 +324,33 @@ class FullBatchGCN(object):
                 self._exchange_rows(plan, col, got)
                 flag = torch.cat([hit.to(got.device), got[:, 0] != 0])
             self.at_wide = filt(plan.csr, flag)
+        self._setup_backward_rows()
+
+    def _setup_backward_rows(self):
+        """When clearly fewer than all rows of dP1 = A^T d(A P1) can be nonzero (the
+        non-empty rows of ``self.at_wide``), the product writes those rows next to each
+        other (``self.hb_c``) and the weight gradient X'^T dP1 sums over them only,
+        against a copy of those rows of the features gathered once (``self.x_c``; the
+        dropout mask of a row is drawn by its id)."""
+        self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
+        compact = getattr(self.k, "csr_compact_rows", None)
+        if self.at_wide is None or compact is None or not hasattr(self.k, "gather_rows"):
+            return
+        if self.keep < 1.0 and not self.fuse_x_dropout:
+            return                                  # dropout(X) is stored per step: nothing to gather once
+        sub, rows = compact(self.at_wide)
+        m = int(sub.n_rows)
+        if not (0 < m <= (self.n_loc * 7) // 10):
+            return
+        if self.keep < 1.0:
+            sup = getattr(self.k, "gemm_supports_a_dropout_rows_t", None)
+            if sup is None or not sup(self.f, self.h, m):
+                return
+        self.at_wide_c, self.hb_rows = sub, rows.to(self.dev)
+        self.x_c = torch.empty((m, self.f), dtype=torch.float32, device=self.dev)
+        self.k.gather_rows(self.x, self.hb_rows, self.x_c)
+        self.hb_c = torch.empty((m, self.h), dtype=torch.float32, device=self.dev)
+        self.hb = None                              # the full-height buffer is not needed
 
     def backward_nnz(self):
         """Nonzeros of the local part of A^T that the hidden-width backward product multiplies."""
@@ -570,7 +597,9 @@ class FullBatchGCN(object):
             k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate_bits=self.hbits, gate_scale=1.0 / keep)
         else:
             k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate=hin, gate_scale=1.0 / keep)
-        # layer 1
+        # layer 1 (rows of dP1 that can be nonzero next to each other when that is set up)
+        bwd_a = self.at_wide_c if self.at_wide_c is not None else self.at_wide
+        bwd_out = self.hb_c if self.at_wide_c is not None else self.hb
         if self.order == "aggregate_first":
             # the gated product is the gradient wrt (A_hat X') W1; X needs none
             k.gemm(self.ax, self.p1, trans_a=True, out=self.g1)            # (A_hat X')^T dZ1
@@ -583,9 +612,9 @@ class FullBatchGCN(object):
             self._bits_work = None
             if self.factored_bwd:
                 # local and halo rows of d(A P1) alike from dP2 rows and sign words
-                k.spmm_factored(self.at_wide if self.at_wide is not None else plan.csr, self.dp2, self.w2,
+                k.spmm_factored(bwd_a if bwd_a is not None else plan.csr, self.dp2, self.w2,
                                 self.hbits, gate_scale=1.0 / keep, trans_w=True,
-                                out=self.hb, d2=self.dp2_halo[:nh] if nh else None,
+                                out=bwd_out, d2=self.dp2_halo[:nh] if nh else None,
                                 gate_bits2=self.hbits_halo[:nh] if nh else None)
             else:
                 if nh:
@@ -593,17 +622,24 @@ class FullBatchGCN(object):
                     # of dP2 and the received sign bits of the owners' H'
                     k.gemm(self.dp2_halo[:nh], self.w2, trans_b=True, out=self.wide_halo[:nh],
                            gate_bits=self.hbits_halo[:nh], gate_scale=1.0 / keep)
-                k.spmm(self.at_wide if self.at_wide is not None else plan.csr, self.p1, out=self.hb,
+                k.spmm(bwd_a if bwd_a is not None else plan.csr, self.p1, out=bwd_out,
                        b2=self.wide_halo[:nh] if nh else None)
         elif self.factored_bwd:
-            k.spmm_factored(self.at_wide if self.at_wide is not None else self.at, self.dp2, self.w2, self.hbits,
-                            gate_scale=1.0 / keep, trans_w=True, out=self.hb)   # A^T dH -> dP1, dH never stored
-        elif self.world == 1 and self.at_wide is not None:
-            k.spmm(self.at_wide, self.p1, out=self.hb)                   # A^T dH -> dP1
+            k.spmm_factored(bwd_a if bwd_a is not None else self.at, self.dp2, self.w2, self.hbits,
+                            gate_scale=1.0 / keep, trans_w=True, out=bwd_out)   # A^T dH -> dP1, dH never stored
+        elif self.world == 1 and bwd_a is not None:
+            k.spmm(bwd_a, self.p1, out=bwd_out)                          # A^T dH -> dP1
         else:
             self._aggregate("bwd", self.p1, self.hb, relu=False)         # A^T dH -> dP1
         if self.order != "aggregate_first":
-            if xdrop is not None:
+            if self.at_wide_c is not None:
+                # over the rows of dP1 that can be nonzero; row i of x_c is row hb_rows[i] of X
+                if xdrop is not None:
+                    k.gemm(self.x_c, self.hb_c, trans_a=True, out=self.g1, a_dropout=xdrop,
+                           a_dropout_rows=self.hb_rows)
+                else:
+                    k.gemm(self.x_c, self.hb_c, trans_a=True, out=self.g1)
+            elif xdrop is not None:
                 k.gemm(xin, self.hb, trans_a=True, out=self.g1, a_dropout=xdrop)  # X'^T dP1, X' regenerated
             else:
                 k.gemm(xin, self.hb, trans_a=True, out=self.g1)                 # X'^T dP1

@@ -219,9 +219,10 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
     backward of relu + dropout fused into the product that feeds it.
     ``a_dropout=(keep, seed, offset)`` applies dropout to ``a`` (as stored,
     row-major with its own row length) while it is read, so dropout(a) is never
-    written (MFMA shapes only); with ``a_dropout_rows`` (int32, one per row of a
-    plain ``a``) row i draws the mask of row ``a_dropout_rows[i]`` (``a`` holds a
-    gathered subset of the rows the mask is defined on).  ``gate_bits`` (uint32 /
+    written (MFMA shapes only); with ``a_dropout_rows`` (int32, one per stored row
+    of ``a``) row i draws the mask of row ``a_dropout_rows[i]`` (``a`` holds a
+    gathered subset of the rows the mask is defined on; with a transposed ``a``
+    only where :func:`gemm_supports_a_dropout_rows_t` says so).  ``gate_bits`` (uint32 /
     int32 [M, ceil(N/32)]) is the gate as one bit per element
     (:func:`pack_sign_bits`).  ``dropout=(keep, seed, offset, ld, col0)`` applies
     dropout to the output behind the activation, as in :func:`spmm`; with it,
@@ -290,13 +291,20 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu
             d = _lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), a.shape[1], 0)
             if a_dropout_rows is not None:
                 r = a_dropout_rows
-                if trans_a or r.dtype != torch.int32 or r.numel() != M or not r.is_contiguous() or \
-                        r.device != a.device:
-                    raise ValueError("a_dropout_rows: one contiguous int32 per row of a plain a")
-                _lib.check(lib.gcnx_gemm_dropout_a_rows_f32(int(trans_b), M, N, K, _ptr(a), a.stride(0),
-                                                            C.byref(d), _ptr(r), _ptr(b), b.stride(0),
-                                                            _ptr(out), out.stride(0), float(alpha),
-                                                            float(beta), _ptr(ws), ws.numel(), _stream()))
+                if r.dtype != torch.int32 or r.numel() != a.shape[0] or not r.is_contiguous() or r.device != a.device:
+                    raise ValueError("a_dropout_rows: one contiguous int32 per stored row of a")
+                if trans_a:
+                    if trans_b:
+                        raise ValueError("a_dropout_rows with a transposed a needs a plain b")
+                    _lib.check(lib.gcnx_gemm_dropout_at_rows_f32(M, N, K, _ptr(a), a.stride(0), C.byref(d), _ptr(r),
+                                                                 _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                                                 float(alpha), float(beta), _ptr(ws), ws.numel(),
+                                                                 _stream()))
+                else:
+                    _lib.check(lib.gcnx_gemm_dropout_a_rows_f32(int(trans_b), M, N, K, _ptr(a), a.stride(0),
+                                                                C.byref(d), _ptr(r), _ptr(b), b.stride(0),
+                                                                _ptr(out), out.stride(0), float(alpha),
+                                                                float(beta), _ptr(ws), ws.numel(), _stream()))
             else:
                 _lib.check(lib.gcnx_gemm_dropout_a_f32(int(trans_a), int(trans_b), M, N, K, _ptr(a),
                                                        a.stride(0), C.byref(d), _ptr(b), b.stride(0),
@@ -412,6 +420,12 @@ class _GemmFn(torch.autograd.Function):
         da = gemm(dy, b, trans_b=True) if ctx.needs_input_grad[0] else None
         db = gemm(a, dy, trans_a=True) if ctx.needs_input_grad[1] else None
         return da, db, None
+
+
+def gemm_supports_a_dropout_rows_t(M, N, K):
+    """Whether ``gemm(a, b, trans_a=True, a_dropout=..., a_dropout_rows=...)`` is
+    served for an [M, N] output summed over K stored rows."""
+    return bool(_lib.load().gcnx_gemm_dropout_at_rows_supported(int(M), int(N), int(K)))
 
 
 def gemm_autograd(a, b, relu=False):

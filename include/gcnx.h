@@ -474,6 +474,18 @@ int gcnx_gemm_dropout_a_rows_f32(int trans_b, int64_t M, int64_t N, int64_t K,
                                  int64_t ldb, float *C, int64_t ldc, float alpha,
                                  float beta, void *ws, size_t ws_bytes, void *stream);
 
+/* The same for the transposed form C[M,N] = dropout(A)^T B with A stored [K, M]:
+ * row k of A draws the mask of row a_row_ids[k] (K ids).  For the weight gradient
+ * X'^T dP1 summed over the rows of dP1 that can be nonzero only: X holds those
+ * rows of the features, gathered once.  Served where
+ * gcnx_gemm_dropout_at_rows_supported says so (split-operand arithmetic, N a
+ * multiple of 256, the tall transposed MFMA shape); GCNX_ERR_UNSUPPORTED otherwise. */
+int gcnx_gemm_dropout_at_rows_supported(int64_t M, int64_t N, int64_t K);
+int gcnx_gemm_dropout_at_rows_f32(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                                  const gcnx_dropout *a_dropout, const int32_t *a_row_ids,
+                                  const float *B, int64_t ldb, float *C, int64_t ldc, float alpha,
+                                  float beta, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- glue kernels of one training step ------------------------------------ */
 
 /* replaces: masked_softmax_cross_entropy + masked_accuracy, gcn/metrics.py:4-20.

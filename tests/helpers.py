@@ -149,6 +149,9 @@ class OracleKernels(object):
     def gemm_supports_output_dropout(self, trans_a, M, N, K):
         return not trans_a and N % 4 == 0
 
+    def gemm_supports_a_dropout_rows_t(self, M, N, K):
+        return True
+
     def gemm_supports_a_dropout(self, trans_a, M, N, K):
         return True
 

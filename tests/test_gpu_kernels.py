@@ -594,6 +594,48 @@ def test_gemm_dropout_on_gathered_rows(env):
     assert torch.equal(got, full[rt.long()])
 
 
+@pytest.mark.parametrize("M,N,full,kept", [(256, 256, 9000, 5000), (128, 512, 20000, 4097), (256, 256, 6000, 6000)])
+def test_gemm_transposed_dropout_on_gathered_rows(env, M, N, full, kept):
+    """dropout(A)^T B summed over a gathered subset of the stored rows, each drawing the
+    mask of its row id (the weight gradient over the rows of dP1 that can be
+    nonzero): equals the full product when B is zero in the other rows; refused
+    where gcnx_gemm_dropout_at_rows_supported says no."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd._lib import GcnxError
+    rng = np.random.RandomState(M + kept)
+    a = torch.from_numpy(rng.standard_normal((full, M)).astype(np.float32)).to(dev)
+    b = rng.standard_normal((full, N)).astype(np.float32)
+    rows = np.sort(rng.choice(full, size=kept, replace=False)).astype(np.int32)
+    zero = np.ones(full, dtype=bool)
+    zero[rows] = False
+    b[zero] = 0.0
+    bt = torch.from_numpy(b).to(dev)
+    rt = torch.from_numpy(rows).to(dev)
+    off = 5 * (1 << 44) + 4 * M * 3
+    assert ops.gemm_supports_a_dropout_rows_t(M, N, kept)
+    want = ops.gemm(a, bt, trans_a=True, a_dropout=(0.5, 77, off))
+    got = ops.gemm(a[rt.long()].contiguous(), bt[rt.long()].contiguous(), trans_a=True, a_dropout=(0.5, 77, off),
+                   a_dropout_rows=rt)
+    # the same products summed in another grouping (the K split differs)
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # against the materialised mask, in fp64
+    m = env["oracle"].bernoulli_mask_at(np.uint64(off) + rows.astype(np.uint64)[:, None] * np.uint64(M) +
+                                        np.arange(M, dtype=np.uint64)[None, :], 0.5, 77)
+    ad = np.where(m != 0, a.cpu().numpy()[rows].astype(np.float64) * 2.0, 0.0)
+    ref = ad.T @ b[rows].astype(np.float64)
+    mag = np.abs(ad).T @ np.abs(b[rows]).astype(np.float64)
+    assert_close_to_f64(got.cpu().numpy(), ref, mag, what="transposed product over gathered rows")
+    before = ops.dense_arith(1)
+    try:
+        assert not ops.gemm_supports_a_dropout_rows_t(M, N, kept)
+        with pytest.raises(GcnxError):
+            ops.gemm(a[rt.long()].contiguous(), bt[rt.long()].contiguous(), trans_a=True, a_dropout=(0.5, 77, off),
+                     a_dropout_rows=rt)
+    finally:
+        ops.dense_arith(before)
+    assert not ops.gemm_supports_a_dropout_rows_t(M, 128, kept)
+
+
 @pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 4096, 256, 256), (0, 0, 3001, 128, 64), (0, 0, 700, 33, 20),
                                          (0, 1, 2048, 64, 16), (0, 0, 5000, 16, 256), (1, 0, 128, 16, 9000)])
 def test_gemm_output_dropout(env, ta, tb, M, N, K):
