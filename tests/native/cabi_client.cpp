@@ -162,6 +162,68 @@ int main() {
                 (long long)kept_cols, (long long)n_cols);
   }
 
+  // ---- sub-matrix of flagged columns: count, fill, and the product with an operand that is
+  //      zero in the other rows ----
+  {
+    std::vector<uint8_t> flag((size_t)n_cols);
+    for (int64_t c2 = 0; c2 < n_cols; ++c2) flag[c2] = (uint8_t)(c2 % 7 == 0);
+    uint8_t *d_flag = dev_alloc<uint8_t>((size_t)n_cols);
+    int64_t *d_rp2 = dev_alloc<int64_t>((size_t)n_rows + 1);
+    const size_t fb = gcnx_csr_filter_workspace_bytes(nnz);
+    void *f_ws = dev_alloc<char>(fb);
+    if (!d_flag || !d_rp2 || !f_ws) return 2;
+    HIP_OK(hipMemcpy(d_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
+    int64_t kept = -1;
+    GCNX_OK_(gcnx_csr_filter_columns_count(&a, d_flag, d_rp2, &kept, f_ws, fb, stream));
+    int64_t want_kept = 0;
+    for (int64_t k = 0; k < nnz; ++k) want_kept += flag[col[k]];
+    if (kept != want_kept || kept <= 0) return 1;
+    int32_t *d_ci2 = dev_alloc<int32_t>((size_t)kept);
+    float *d_v2 = dev_alloc<float>((size_t)kept);
+    if (!d_ci2 || !d_v2) return 2;
+    // a count that is not the one the workspace holds is refused
+    if (gcnx_csr_filter_columns_fill(&a, f_ws, fb, kept - 1, d_ci2, d_v2, nullptr, stream) != GCNX_ERR_INVALID_ARG) return 1;
+    GCNX_OK_(gcnx_csr_filter_columns_fill(&a, f_ws, fb, kept, d_ci2, d_v2, nullptr, stream));
+    std::vector<int32_t> ci2((size_t)kept);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(ci2.data(), d_ci2, ci2.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < kept; ++k)
+      if (!flag[ci2[k]]) return 1;
+    gcnx_csr sub = a;
+    sub.nnz = kept;
+    sub.row_ptr = d_rp2;
+    sub.col_idx = d_ci2;
+    sub.val = d_v2;
+    // operand: the rows of b outside the flagged set zeroed
+    std::vector<float> bz(b);
+    for (int64_t r2 = 0; r2 < n_cols; ++r2)
+      if (!flag[r2])
+        for (int j = 0; j < width; ++j) bz[(size_t)r2 * width + j] = 0.0f;
+    float *d_bz = dev_alloc<float>(bz.size());
+    float *d_cf = dev_alloc<float>((size_t)n_rows * width), *d_cs = dev_alloc<float>((size_t)n_rows * width);
+    int32_t *d_chunk2 = dev_alloc<int32_t>((size_t)gcnx_spmm_num_chunks(kept) + 1);
+    if (!d_bz || !d_cf || !d_cs || !d_chunk2) return 2;
+    HIP_OK(hipMemcpy(d_bz, bz.data(), bz.size() * 4, hipMemcpyHostToDevice));
+    GCNX_OK_(gcnx_spmm_chunk_table(&sub, d_chunk2, stream));
+    GCNX_OK_(gcnx_spmm_csr_f32(&a, d_chunk, d_bz, width, d_cf, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 0,
+                               sp_ws, sp_bytes, stream));
+    GCNX_OK_(gcnx_spmm_csr_f32(&sub, d_chunk2, d_bz, width, d_cs, width, width, 1.0f, 0.0f, nullptr, nullptr, 1.0f, 0,
+                               sp_ws, sp_bytes, stream));
+    std::vector<float> cf((size_t)n_rows * width), cs((size_t)n_rows * width);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(cf.data(), d_cf, cf.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(cs.data(), d_cs, cs.size() * 4, hipMemcpyDeviceToHost));
+    double top = 0.0, apart = 0.0;
+    for (size_t i = 0; i < cf.size(); ++i) {
+      top = std::fabs((double)cf[i]) > top ? std::fabs((double)cf[i]) : top;
+      const double d = std::fabs((double)cf[i] - (double)cs[i]);
+      apart = d > apart ? d : apart;
+    }
+    std::printf("column filter: %lld of %lld nonzeros kept, products %.3g apart (largest entry %.3g)\n",
+                (long long)kept, (long long)nnz, apart, top);
+    if (!(apart <= 1e-6 * top)) return 1;
+  }
+
   // ---- dense product ---------------------------------------------------------
   std::vector<float> ha((size_t)M * K), hb((size_t)K * N), hc((size_t)M * N);
   for (auto &v : ha) v = (float)urand();
