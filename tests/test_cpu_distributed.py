@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers import CpuCsr, OracleKernels  # noqa: E402
 
 
-def _problem(scale=7, f=12, hidden=16, classes=5):
+def _problem(scale=7, f=12, hidden=16, classes=5, label_rate=0.3):
     import oracle
     from gcn_amd import utils
     n = 1 << scale
@@ -29,16 +29,17 @@ def _problem(scale=7, f=12, hidden=16, classes=5):
     w1 = (rng.uniform(-1, 1, (f, hidden)) * 0.3).astype(np.float32)
     w2 = (rng.uniform(-1, 1, (hidden, classes)) * 0.3).astype(np.float32)
     labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
-    lmask = (rng.random_sample(n) < 0.3).astype(np.uint8)
+    lmask = (rng.random_sample(n) < label_rate).astype(np.uint8)
     return n, a_hat, x, w1, w2, labels, lmask, hidden, classes
 
 
 def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5,
-         classes=5, uneven=False):
+         classes=5, uneven=False, label_rate=0.3, scale=7):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(hidden=hidden, classes=classes)
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(scale=scale, hidden=hidden, classes=classes,
+                                                                   label_rate=label_rate)
     if uneven:
         # row ranges of different sizes (N does not divide by the rank count)
         cuts = [0] + [int(round((p + 1) * n / world + (3 if p % 2 == 0 and p + 1 < world else 0)))
@@ -68,7 +69,10 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
     ev = eng.evaluate().numpy().copy()
     np.savez(os.path.join(out_dir, "w%d_r%d%s.npz" % (world, rank, tag)), outs=np.stack(outs), ev=ev,
-             w1=eng.w1.numpy(), w2=eng.w2.numpy(), z=eng.z.numpy())
+             w1=eng.w1.numpy(), w2=eng.w2.numpy(), z=eng.z.numpy(),
+             compact=np.array([eng.at_dz is not None, eng.at_dz_c is not None, eng.at_wide is not None,
+                               eng.at_wide_c is not None]),
+             nnz=np.array([eng.loss_gradient_nnz(), eng.backward_nnz()]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -105,6 +109,33 @@ def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden, classes)
     np.testing.assert_allclose(r0["w1"], one["w1"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
     z = np.concatenate([np.load(os.path.join(out, "w%d_r%d.npz" % (world, r)))["z"] for r in range(world)])
+    np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
+
+
+@pytest.mark.parametrize("world,hidden,classes,dropout", [(2, 64, 16, 0.5), (2, 32, 5, 0.5), (4, 64, 16, 0.0)])
+def test_few_labels_ranks_match_one_rank(tmp_path, world, hidden, classes, dropout):
+    """Few labelled nodes: the backward products run over the rows and columns the
+    labelled nodes reach (sub-matrices, rows formed next to each other, the weight
+    gradient over those rows with the dropout mask drawn by row id) -- on one rank and
+    on several, where the owners tell which halo rows qualify.  Same losses, weights
+    and logits; the sub-matrices of the ranks add up to the one of a single rank."""
+    out = str(tmp_path)
+    _run(0, 1, 0, None, out, "auto", hidden, "reference", "", dropout, classes, False, 0.03, 8)
+    mp.spawn(_run, args=(world, _free_port(), 16, out, "recompute", hidden, "reference", "", dropout, classes, False,
+                         0.03, 8), nprocs=world, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    ranks = [np.load(os.path.join(out, "w%d_r%d.npz" % (world, r))) for r in range(world)]
+    assert one["compact"].all()                       # every shortcut is in use on the single rank
+    assert all(r["compact"][0] and r["compact"][2] for r in ranks)
+    assert any(r["compact"][1] for r in ranks) and any(r["compact"][3] for r in ranks)
+    assert np.array_equal(sum(r["nnz"] for r in ranks), one["nnz"])
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["w1"], r["w1"]) and np.array_equal(ranks[0]["outs"], r["outs"])
+    np.testing.assert_allclose(ranks[0]["outs"], one["outs"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ranks[0]["ev"], one["ev"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ranks[0]["w1"], one["w1"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ranks[0]["w2"], one["w2"], rtol=0, atol=2e-6)
+    z = np.concatenate([r["z"] for r in ranks])
     np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
 
 
