@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="several GPUs over RCCL: per-step halo exchange / all-reduce through the C ABI "
                          "(gcnx_halo_allgather_f32, default) or through torch.distributed")
+    ap.add_argument("--dense-side-steps", type=int, default=3,
+                    help="after the timed steps, time this many steps with the dense backward products as a side "
+                         "measurement (ms_per_step_dense_gradients; 0 = skip)")
     ap.add_argument("--dense-loss-gradient", action="store_true",
                     help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
                          "labelled columns only (the other rows of dZ are exactly zero; same result)")
@@ -328,6 +331,24 @@ def main():
     dt = float(t.item())
     loss_acc = out.cpu().tolist()
 
+    # Side measurement, outside the timed region and not part of `value`: the same
+    # engine with every backward product over every nonzero and row (what
+    # --dense-loss-gradient times as the main number), so that both forms come from one run.
+    dense_ms = None
+    if not args.dense_loss_gradient and model.at_dz is not None and args.dense_side_steps > 0:
+        model.use_dense_gradients()
+        model.train_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.dense_side_steps):
+            model.train_step()
+        barrier()
+        td = torch.tensor([time.perf_counter() - t1], dtype=torch.float64,
+                          device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(td, op=dist.ReduceOp.MAX, group=group)
+        dense_ms = float(td.item()) / args.dense_side_steps * 1e3
+
     if rank == 0:
         # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
         units = model.spmm_units_per_step(nnz_global, nnz_dz_global, nnz_bwd_global)
@@ -361,6 +382,7 @@ def main():
                                    % (nnz_dz_global, nnz_bwd_global))),
             },
             "epoch_ms": dt / args.steps * 1e3,
+            "ms_per_step_dense_gradients": dense_ms,
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,
         }

@@ -352,6 +352,15 @@ class FullBatchGCN(object):
         self.hb_c = torch.empty((m, self.h), dtype=torch.float32, device=self.dev)
         self.hb = None                              # the full-height buffer is not needed
 
+    def use_dense_gradients(self):
+        """From now on every backward product runs over every nonzero and row, as
+        with ``sparse_loss_gradient=False`` (for measuring the two forms in one
+        process; not reversible)."""
+        self.at_dz = self.at_dz_c = self.dz_rows = None
+        self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
+        if self.hb is None and self.order != "aggregate_first":
+            self.hb = torch.empty((self.n_loc, self.h), dtype=torch.float32, device=self.dev)
+
     def backward_nnz(self):
         """Nonzeros of the local part of A^T that the hidden-width backward product multiplies."""
         if self.at_wide is not None:
