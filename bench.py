@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="several GPUs over RCCL: per-step halo exchange / all-reduce through the C ABI "
                          "(gcnx_halo_allgather_f32, default) or through torch.distributed")
+    ap.add_argument("--label-every", type=int, default=100,
+                    help="every how many-th node is labelled (default 100: 1 %% of the nodes)")
     ap.add_argument("--dense-side-steps", type=int, default=3,
                     help="after the timed steps, time this many steps with the dense backward products as a side "
                          "measurement (ms_per_step_dense_gradients; 0 = skip)")
@@ -196,8 +198,8 @@ def main():
     labels = torch.zeros((n_loc, args.classes), dtype=torch.float32, device=dev)
     labels.scatter_(1, cls.view(-1, 1), 1.0)
     gid = torch.arange(rb, re_, device=dev)
-    lmask = (gid % 100 == 0).to(torch.uint8)      # 1 % of the nodes are labelled
-    mask_total = (n + 99) // 100
+    lmask = (gid % args.label_every == 0).to(torch.uint8)      # default: 1 % of the nodes are labelled
+    mask_total = (n + args.label_every - 1) // args.label_every
     del cls, u, gid
 
     engine_cls = engine.FullBatchGCN
@@ -364,7 +366,7 @@ def main():
                 "workload": "RMAT scale %d (2^%d nodes), avg degree %d, F=%d, hidden %d, %d classes, "
                             "2-layer GCN, dropout 0.5, Adam" % (scale, scale, 2 * args.edge_factor,
                                                                 args.features, args.hidden, args.classes),
-                "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
+                "labelled_nodes": mask_total, "nnz_a_hat": nnz_global, "rows_per_gpu": n_loc, "parallelism": "row-partition x%d" % world,
                 "halo_rows_rank0": (model.plan.n_halo if model.plan is not None else 0),
                 "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
