@@ -50,7 +50,8 @@ from . import ops as _hip_ops
 class _SubPlan(object):
     """The part of a halo plan an exchange needs (send_idx, per-peer counts), for a
     subset of the plan's rows."""
-    __slots__ = ("send_idx", "send_counts", "recv_counts", "n_send", "n_halo", "halo_pos", "send_buf", "recv_buf")
+    __slots__ = ("send_idx", "send_counts", "recv_counts", "n_send", "n_halo", "halo_pos", "send_buf", "recv_buf",
+                 "send_bits", "recv_bits")
 
 
 class FullBatchGCN(object):
@@ -227,6 +228,39 @@ class FullBatchGCN(object):
         self._bits_work = None
         return True
 
+    def _flagged_subplan(self, plan, local_flag):
+        """The part of ``plan`` that concerns the flagged rows (``local_flag``: one
+        bool per local row): every owner tells its requesters which of the rows they
+        asked for are flagged (one exchange of a 0/1 column through the plan, at
+        set-up).  Returns the sub-plan (send_idx, per-peer counts, positions of the
+        flagged rows among the halo rows) and the flags of the halo rows."""
+        flag = local_flag.to(torch.float32).view(-1, 1).contiguous().to(self.dev)
+        got = torch.zeros((max(plan.n_halo, 1), 1), dtype=torch.float32, device=self.dev)
+        self._exchange_rows(plan, flag, got)
+
+        def per_peer(marks, counts):
+            out, lo = [], 0
+            m = marks.to("cpu")
+            for c in counts:
+                out.append(int(m[lo:lo + c].sum().item()))
+                lo += c
+            return out
+
+        sub = _SubPlan()
+        if plan.n_send:
+            on_s = flag[plan.send_idx.long(), 0] != 0
+            sub.send_idx = plan.send_idx[on_s].contiguous()
+            sub.send_counts = per_peer(on_s, plan.send_counts)
+        else:
+            sub.send_idx = torch.empty(0, dtype=torch.int32, device=self.dev)
+            sub.send_counts = [0] * self.world
+        on_h = got[:plan.n_halo, 0] != 0
+        sub.halo_pos = torch.nonzero(on_h).view(-1).to(torch.int32).contiguous()
+        sub.recv_counts = per_peer(on_h, plan.recv_counts)
+        sub.n_send, sub.n_halo = int(sub.send_idx.numel()), int(sub.halo_pos.numel())
+        sub.send_buf = sub.recv_buf = None
+        return sub, on_h
+
     # ------------------------------------------- loss gradient: labelled rows only
     def _setup_label_exchange(self):
         """dZ = (softmax - y) * mask / total is exactly zero outside the labelled
@@ -241,31 +275,8 @@ class FullBatchGCN(object):
         self.dz_plan = None
         if scatter is None:
             return
-        flag = (self.ymask != 0).to(torch.float32).view(-1, 1).contiguous()
-        got = torch.zeros((max(plan.n_halo, 1), 1), dtype=torch.float32, device=self.dev)
-        self._exchange_rows(plan, flag, got)
-
-        def per_peer(marks, counts):
-            out, lo = [], 0
-            m = marks.to("cpu")
-            for c in counts:
-                out.append(int(m[lo:lo + c].sum().item()))
-                lo += c
-            return out
-
-        sub = _SubPlan()
-        if plan.n_send:
-            lab_s = flag[plan.send_idx.long(), 0] != 0
-            sub.send_idx = plan.send_idx[lab_s].contiguous()
-            sub.send_counts = per_peer(lab_s, plan.send_counts)
-        else:
-            sub.send_idx = torch.empty(0, dtype=torch.int32, device=self.dev)
-            sub.send_counts = [0] * self.world
-        lab_h = got[:plan.n_halo, 0] != 0
+        sub, lab_h = self._flagged_subplan(plan, self.ymask != 0)
         self.dz_halo_labelled = lab_h
-        sub.halo_pos = torch.nonzero(lab_h).view(-1).to(torch.int32).contiguous()
-        sub.recv_counts = per_peer(lab_h, plan.recv_counts)
-        sub.n_send, sub.n_halo = int(sub.send_idx.numel()), int(sub.halo_pos.numel())
         sub.send_buf = torch.empty((max(sub.n_send, 1), self.c), dtype=torch.float32, device=self.dev)
         sub.recv_buf = torch.empty((max(sub.n_halo, 1), self.c), dtype=torch.float32, device=self.dev)
         # halo rows of dZ: zero for good, except the labelled ones (rewritten every step)
@@ -307,6 +318,7 @@ class FullBatchGCN(object):
         zero unless the node has a labelled neighbour (or is labelled): the rows of
         ``self.at_dz`` that hold a nonzero.  None: the full matrix."""
         self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
+        self.hit_plan = None
         filt = getattr(self.k, "csr_filter_columns", None)
         if self.at_dz is None or filt is None or self.order == "aggregate_first":
             return
@@ -316,14 +328,21 @@ class FullBatchGCN(object):
             self.at_wide = filt(self.at, hit)
         elif self.recompute:
             plan = self.plan
-            flag = hit
-            if plan.n_halo:
-                # the owners tell which of the requested rows can be nonzero (set-up, once)
-                col = hit.to(torch.float32).view(-1, 1).contiguous().to(self.dev)
-                got = torch.zeros((plan.n_halo, 1), dtype=torch.float32, device=self.dev)
-                self._exchange_rows(plan, col, got)
-                flag = torch.cat([hit.to(got.device), got[:, 0] != 0])
+            # the owners tell which of the requested rows can be nonzero (set-up, once); only
+            # those rows of dP2 and of the sign words of H' travel from here on
+            sub, hit_h = self._flagged_subplan(plan, hit)
+            flag = torch.cat([hit.to(hit_h.device), hit_h]) if plan.n_halo else hit
             self.at_wide = filt(plan.csr, flag)
+            if hasattr(self.k, "scatter_rows"):
+                words = self.h // 32
+                e = lambda *sh, **kw: torch.empty(sh, dtype=kw.get("dtype", torch.float32), device=self.dev)
+                sub.send_buf, sub.recv_buf = e(max(sub.n_send, 1), self.c), e(max(sub.n_halo, 1), self.c)
+                sub.send_bits = e(max(sub.n_send, 1), words, dtype=torch.int32)
+                sub.recv_bits = e(max(sub.n_halo, 1), words, dtype=torch.int32)
+                # rows that do not qualify are never read by the filtered product; kept zero all the same
+                self.dp2_halo.zero_()
+                self.hbits_halo.zero_()
+                self.hit_plan = sub
         self._setup_backward_rows()
 
     def _setup_backward_rows(self):
@@ -552,9 +571,18 @@ class FullBatchGCN(object):
                 if self.hbits is not None:
                     # the SpMM already wrote the sign words of every local row: the
                     # requested rows are picked (32 bytes each, a bit-preserving copy) and sent
-                    self._bits_work = self._exchange_start(
-                        plan, self.hbits.view(torch.float32), 0, self.hbits.shape[1],
-                        self.hbits_send[:plan.n_send].view(torch.float32), self.hbits_halo[:nh].view(torch.float32))
+                    sub = self.hit_plan
+                    if sub is not None:
+                        # only the rows whose gradient can be nonzero (placed when waited for)
+                        self._bits_work = self._exchange_start(
+                            sub, self.hbits.view(torch.float32), 0, self.hbits.shape[1],
+                            sub.send_bits[:sub.n_send].view(torch.float32),
+                            sub.recv_bits[:sub.n_halo].view(torch.float32))
+                    else:
+                        self._bits_work = self._exchange_start(
+                            plan, self.hbits.view(torch.float32), 0, self.hbits.shape[1],
+                            self.hbits_send[:plan.n_send].view(torch.float32),
+                            self.hbits_halo[:nh].view(torch.float32))
                 else:
                     if plan.n_send:
                         k.pack_sign_bits(self.hd, rows=plan.send_idx, out=self.hbits_send[:plan.n_send])
@@ -591,8 +619,13 @@ class FullBatchGCN(object):
         dp2_work = None
         if self.recompute:
             plan = self.plan
-            dp2_work = self._exchange_start(plan, self.dp2, 0, self.c, self.dp2_send[:plan.n_send],
-                                            self.dp2_halo[:plan.n_halo])
+            sub = self.hit_plan
+            if sub is not None:
+                dp2_work = self._exchange_start(sub, self.dp2, 0, self.c, sub.send_buf[:sub.n_send],
+                                                sub.recv_buf[:sub.n_halo])
+            else:
+                dp2_work = self._exchange_start(plan, self.dp2, 0, self.c, self.dp2_send[:plan.n_send],
+                                                self.dp2_halo[:plan.n_halo])
         if self.at_dz_c is not None:
             # the rows of dP2 that can be nonzero, and the same rows of H'
             k.gather_rows(hin, self.dz_rows, self.hd_c)
@@ -619,6 +652,13 @@ class FullBatchGCN(object):
                 if work is not None:
                     work.wait()
             self._bits_work = None
+            sub = self.hit_plan
+            if sub is not None and sub.n_halo:
+                # the received rows go to their places among the halo rows
+                k.scatter_rows(sub.recv_buf[:sub.n_halo], sub.halo_pos, self.dp2_halo)
+                if self.hbits is not None:
+                    k.scatter_rows(sub.recv_bits[:sub.n_halo].view(torch.float32), sub.halo_pos,
+                                   self.hbits_halo.view(torch.float32))
             if self.factored_bwd:
                 # local and halo rows of d(A P1) alike from dP2 rows and sign words
                 k.spmm_factored(bwd_a if bwd_a is not None else plan.csr, self.dp2, self.w2,

@@ -72,7 +72,9 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
              w1=eng.w1.numpy(), w2=eng.w2.numpy(), z=eng.z.numpy(),
              compact=np.array([eng.at_dz is not None, eng.at_dz_c is not None, eng.at_wide is not None,
                                eng.at_wide_c is not None]),
-             nnz=np.array([eng.loss_gradient_nnz(), eng.backward_nnz()]))
+             nnz=np.array([eng.loss_gradient_nnz(), eng.backward_nnz()]),
+             halo=np.array([eng.plan.n_halo, eng.hit_plan.n_halo if eng.hit_plan is not None else -1]
+                           if world > 1 else [0, 0]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -129,6 +131,8 @@ def test_few_labels_ranks_match_one_rank(tmp_path, world, hidden, classes, dropo
     assert all(r["compact"][0] and r["compact"][2] for r in ranks)
     assert any(r["compact"][1] for r in ranks) and any(r["compact"][3] for r in ranks)
     assert np.array_equal(sum(r["nnz"] for r in ranks), one["nnz"])
+    # of the halo rows of dP2 and of the sign words only those whose gradient can be nonzero travel
+    assert all(0 <= r["halo"][1] < r["halo"][0] for r in ranks)
     for r in ranks[1:]:
         assert np.array_equal(ranks[0]["w1"], r["w1"]) and np.array_equal(ranks[0]["outs"], r["outs"])
     np.testing.assert_allclose(ranks[0]["outs"], one["outs"], rtol=1e-5, atol=1e-7)
