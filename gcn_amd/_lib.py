@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCNX_LIB overrides the path (kernel-variant experiments during development)
 LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 SPMM_STATIC_SCRATCH_BYTES = 32 << 20   # GCNX_SPMM_STATIC_SCRATCH_BYTES of include/gcnx.h
 
 OK = 0

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GCNX_ABI_VERSION 3
+#define GCNX_ABI_VERSION 4
 
 typedef enum gcnx_status {
   GCNX_OK = 0,
