@@ -377,6 +377,7 @@ class FullBatchGCN(object):
         process; not reversible)."""
         self.at_dz = self.at_dz_c = self.dz_rows = None
         self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
+        self.hit_plan = None                        # every halo row of dP2 and of the sign words travels again
         if self.hb is None and self.order != "aggregate_first":
             self.hb = torch.empty((self.n_loc, self.h), dtype=torch.float32, device=self.dev)
 
