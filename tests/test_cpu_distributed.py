@@ -204,6 +204,32 @@ def test_two_ranks_without_dropout(tmp_path, halo_mode, order):
     np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
 
 
+def test_dense_and_shortcut_gradients_agree():
+    """The backward products over the rows and columns the labelled nodes reach against
+    every product over every nonzero and row: same losses, same weights (sums that
+    differ by exact zeros, grouped differently); and an engine switched over in
+    mid-run (use_dense_gradients) continues as the dense one."""
+    from gcn_amd import engine
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(scale=8, hidden=64, classes=16, label_rate=0.03)
+    T = torch.from_numpy
+    mk = lambda sparse: engine.FullBatchGCN(
+        CpuCsr(a_hat), T(x.copy()), T(labels.copy()), T(lmask.copy()), int(lmask.sum()), hidden, classes, T(w1), T(w2),
+        seed=5, kernels=OracleKernels(), sparse_loss_gradient=sparse)
+    short, dense, mixed = mk(True), mk(False), mk(True)
+    assert short.at_dz_c is not None and short.at_wide_c is not None and dense.at_dz is None
+    for step in range(3):
+        if step == 1:
+            mixed.use_dense_gradients()
+            assert mixed.at_dz is None and mixed.at_wide_c is None and mixed.hb is not None
+        outs = [e.train_step().numpy().copy() for e in (short, dense, mixed)]
+        np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(outs[2], outs[1], rtol=1e-5, atol=1e-7)
+        for e in (short, mixed):
+            np.testing.assert_allclose(e.w1.numpy(), dense.w1.numpy(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(e.w2.numpy(), dense.w2.numpy(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(e.g1.numpy(), dense.g1.numpy(), rtol=0, atol=1e-5 * np.abs(dense.g1.numpy()).max())
+
+
 def test_single_rank_matches_model_oracle():
     """The engine's schedule (buffer reuse, fused backward steps) against the
     independent model restatement in oracle/model.py."""
