@@ -129,6 +129,8 @@ def main():
                     help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
                          "labelled columns only (the other rows of dZ are exactly zero; same result)")
     args = ap.parse_args()
+    if args.label_every < 1:
+        raise SystemExit("--label-every must be at least 1")
 
     t_start = time.time()
     import torch
