@@ -287,7 +287,7 @@ class FullBatchGCN(object):
         """``self.at_dz``: the matrix of the product A^T dZ restricted to the columns
         whose dZ row can be nonzero (labelled local rows and labelled halo rows), or
         None (the full matrix is used)."""
-        self.at_dz = self.at_dz_c = self.dz_rows = None
+        self.at_dz = self.at_dz_c = self.dz_rows = self.p1_c = self.ax_c = None
         filt = getattr(self.k, "csr_filter_columns", None)
         if not enabled or filt is None:
             return
@@ -310,6 +310,10 @@ class FullBatchGCN(object):
                 self.dp2_c = torch.empty((sub.n_rows, self.c), dtype=torch.float32, device=self.dev)
                 self.hd_c = torch.empty((sub.n_rows, self.h), dtype=torch.float32, device=self.dev)
                 self.dp2.zero_()
+                if self.order == "aggregate_first":
+                    # the gated product and the weight gradient (A_hat X')^T dZ1 over those rows only
+                    self.p1_c = torch.empty((sub.n_rows, self.h), dtype=torch.float32, device=self.dev)
+                    self.ax_c = torch.empty((sub.n_rows, self.f), dtype=torch.float32, device=self.dev)
 
     def _setup_backward_matrix(self):
         """``self.at_wide``: the matrix of the hidden-width backward product
@@ -375,7 +379,7 @@ class FullBatchGCN(object):
         """From now on every backward product runs over every nonzero and row, as
         with ``sparse_loss_gradient=False`` (for measuring the two forms in one
         process; not reversible)."""
-        self.at_dz = self.at_dz_c = self.dz_rows = None
+        self.at_dz = self.at_dz_c = self.dz_rows = self.p1_c = self.ax_c = None
         self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
         self.hit_plan = None                        # every halo row of dP2 and of the sign words travels again
         if self.hb is None and self.order != "aggregate_first":
@@ -634,8 +638,12 @@ class FullBatchGCN(object):
         else:
             k.gemm(hin, self.dp2, trans_a=True, out=self.g2)                # H'^T dP2
         # d(A P1) = (H' > 0) ? (dP2 W2^T) / keep : 0, gate applied in the epilogue
+        agg_rows = self.order == "aggregate_first" and self.p1_c is not None
         if self.factored_bwd:
             pass                            # formed per nonzero inside the SpMM below
+        elif agg_rows:
+            # a row of the gated product is zero where the row of dP2 is: the others only
+            k.gemm(self.dp2_c, self.w2, trans_b=True, out=self.p1_c, gate=self.hd_c, gate_scale=1.0 / keep)
         elif self.hbits is not None:
             k.gemm(self.dp2, self.w2, trans_b=True, out=self.p1, gate_bits=self.hbits, gate_scale=1.0 / keep)
         else:
@@ -645,7 +653,11 @@ class FullBatchGCN(object):
         bwd_out = self.hb_c if self.at_wide_c is not None else self.hb
         if self.order == "aggregate_first":
             # the gated product is the gradient wrt (A_hat X') W1; X needs none
-            k.gemm(self.ax, self.p1, trans_a=True, out=self.g1)            # (A_hat X')^T dZ1
+            if agg_rows:
+                k.gather_rows(self.ax, self.dz_rows, self.ax_c)
+                k.gemm(self.ax_c, self.p1_c, trans_a=True, out=self.g1)    # (A_hat X')^T dZ1 over its nonzero rows
+            else:
+                k.gemm(self.ax, self.p1, trans_a=True, out=self.g1)        # (A_hat X')^T dZ1
         elif self.recompute:
             plan = self.plan
             nh = plan.n_halo

@@ -204,7 +204,8 @@ def test_two_ranks_without_dropout(tmp_path, halo_mode, order):
     np.testing.assert_allclose(r0["w2"], one["w2"], rtol=0, atol=2e-6)
 
 
-def test_dense_and_shortcut_gradients_agree():
+@pytest.mark.parametrize("order", ["reference", "aggregate_first"])
+def test_dense_and_shortcut_gradients_agree(order):
     """The backward products over the rows and columns the labelled nodes reach against
     every product over every nonzero and row: same losses, same weights (sums that
     differ by exact zeros, grouped differently); and an engine switched over in
@@ -214,13 +215,16 @@ def test_dense_and_shortcut_gradients_agree():
     T = torch.from_numpy
     mk = lambda sparse: engine.FullBatchGCN(
         CpuCsr(a_hat), T(x.copy()), T(labels.copy()), T(lmask.copy()), int(lmask.sum()), hidden, classes, T(w1), T(w2),
-        seed=5, kernels=OracleKernels(), sparse_loss_gradient=sparse)
+        seed=5, kernels=OracleKernels(), sparse_loss_gradient=sparse, order=order)
     short, dense, mixed = mk(True), mk(False), mk(True)
-    assert short.at_dz_c is not None and short.at_wide_c is not None and dense.at_dz is None
+    assert short.at_dz_c is not None and dense.at_dz is None
+    assert (short.at_wide_c is not None) == (order == "reference")
+    assert (short.p1_c is not None) == (order == "aggregate_first")
     for step in range(3):
         if step == 1:
             mixed.use_dense_gradients()
-            assert mixed.at_dz is None and mixed.at_wide_c is None and mixed.hb is not None
+            assert mixed.at_dz is None and mixed.at_wide_c is None and mixed.p1_c is None
+            assert (mixed.hb is not None) == (order == "reference")
         outs = [e.train_step().numpy().copy() for e in (short, dense, mixed)]
         np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(outs[2], outs[1], rtol=1e-5, atol=1e-7)

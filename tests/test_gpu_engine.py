@@ -71,7 +71,8 @@ def _dense_tuple(x):
     (128, 16, "reference-dense-dz", 9, 48),
     # few labelled nodes: the rows of dP2 that can be nonzero are formed next to each
     # other and H'^T dP2 sums over those rows only
-    (256, 16, "reference-few-labels", 11, 128), (16, 7, "reference-few-labels", 10, 48)])
+    (256, 16, "reference-few-labels", 11, 128), (16, 7, "reference-few-labels", 10, 48),
+    (128, 16, "aggregate_first-few-labels", 11, 64)])
 def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
