@@ -288,6 +288,8 @@ class FullBatchGCN(object):
         whose dZ row can be nonzero (labelled local rows and labelled halo rows), or
         None (the full matrix is used)."""
         self.at_dz = self.at_dz_c = self.dz_rows = self.p1_c = self.ax_c = None
+        # the sub-matrices below are derived from the label mask as it is now
+        self._mask_version = getattr(self.ymask, "_version", None)
         filt = getattr(self.k, "csr_filter_columns", None)
         if not enabled or filt is None:
             return
@@ -610,6 +612,10 @@ class FullBatchGCN(object):
         """One optimisation step.  Returns a 2-element device tensor
         [cross-entropy part of the loss, accuracy] (before the update)."""
         k = self.k
+        if (self.at_dz is not None or self.dz_plan is not None) and \
+                getattr(self.ymask, "_version", None) != self._mask_version:
+            raise RuntimeError("the label mask was modified after the engine was set up; its backward "
+                               "sub-matrices and exchanges are derived from it: build a new engine")
         self.step_no += 1
         xin, hin, xdrop = self.forward(train=True)
         out = self.loss(want_grad=True)

@@ -234,6 +234,21 @@ def test_dense_and_shortcut_gradients_agree(order):
             np.testing.assert_allclose(e.g1.numpy(), dense.g1.numpy(), rtol=0, atol=1e-5 * np.abs(dense.g1.numpy()).max())
 
 
+def test_modified_label_mask_is_refused():
+    """The backward sub-matrices are built from the label mask at set-up: a mask
+    modified in place afterwards is an error, not a silently wrong gradient."""
+    from gcn_amd import engine
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(scale=7, label_rate=0.05)
+    T = torch.from_numpy
+    mask = T(lmask.copy())
+    eng = engine.FullBatchGCN(CpuCsr(a_hat), T(x.copy()), T(labels.copy()), mask, int(lmask.sum()), hidden, classes,
+                              T(w1), T(w2), seed=5, kernels=OracleKernels())
+    eng.train_step()
+    mask[3] = 1 - mask[3]
+    with pytest.raises(RuntimeError, match="label mask"):
+        eng.train_step()
+
+
 def test_single_rank_matches_model_oracle():
     """The engine's schedule (buffer reuse, fused backward steps) against the
     independent model restatement in oracle/model.py."""
