@@ -830,6 +830,29 @@ def test_filter_columns_keeps_flagged_nonzeros_in_order(env, n, n_cols, nnz, fra
         a.filter_columns(torch.zeros(n_cols + 1, dtype=torch.uint8, device=dev))
 
 
+def test_compact_rows_then_scatter_equals_the_full_product(env):
+    """Csr.compact_rows: the product with the matrix without its empty rows, put in
+    place with scatter_rows into a zeroed result, equals the full product (whose
+    empty rows are zero rows)."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(4)
+    n, n_cols = 4000, 3000
+    rows, cols, vals = random_coo(rng, n, n_cols, 9000, hub_rows=((9, 2000),), empty_rows=(0, 1, n - 1))
+    a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n_cols), device=dev)
+    sub, ids = a.compact_rows()
+    deg = np.diff(a.row_ptr.cpu().numpy())
+    assert np.array_equal(ids.cpu().numpy(), np.nonzero(deg > 0)[0]) and sub.n_rows == int((deg > 0).sum()) < n
+    assert sub.nnz == a.nnz and sub.col_idx.data_ptr() == a.col_idx.data_ptr()
+    for width in (16, 256):
+        b = torch.from_numpy(rng.standard_normal((n_cols, width)).astype(np.float32)).to(dev)
+        full = ops.spmm(a, b)
+        part = ops.spmm(sub, b)
+        out = torch.zeros_like(full)
+        ops.scatter_rows(part, ids, out)
+        assert torch.equal(out, full)
+
+
 @pytest.fixture(params=["split_bf16", "f32_chain"])
 def dense_arith(request, env):
     """Both arithmetic modes of the large dense products: exactly split operands
