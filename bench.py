@@ -93,13 +93,104 @@ def cpu_baseline(a, b_dev, rows, width):
     }
 
 
+def cpu_epoch_baseline(scale, args, dev):
+    """The oracle's restatement of one full training epoch of the reference's
+    two-layer GCN (forward, masked loss, backward, Adam; TensorFlow CPU order,
+    one thread) timed on a small RMAT instance of the benchmark's shape, next to
+    the GPU engine's step on the very same instance and inputs."""
+    import numpy as np
+    import torch
+    import oracle
+    from oracle import model as omodel
+    from gcn_amd import engine, ops, rmat
+    oracle.build()
+    n, f, h, c = 1 << scale, args.features, args.hidden, args.classes
+    a = rmat.rmat_ahat(scale, 8, 123, dev)
+    x = ops.philox_uniform((n, f), -1.0, 1.0, 124, 0, dev)
+    r1, r2 = math.sqrt(6.0 / (f + h)), math.sqrt(6.0 / (h + c))
+    w1 = ops.philox_uniform((f, h), -r1, r1, 125, 0, dev)
+    w2 = ops.philox_uniform((h, c), -r2, r2, 125, 1 << 40, dev)
+    cls = ops.philox_uniform((n,), 0.0, float(c), 126, 0, dev).to(torch.int64).clamp_(0, c - 1)
+    labels = torch.zeros((n, c), dtype=torch.float32, device=dev)
+    labels.scatter_(1, cls.view(-1, 1), 1.0)
+    lmask = (torch.arange(n, device=dev) % args.label_every == 0).to(torch.uint8)
+    total = int(lmask.sum().item())
+    eng = engine.FullBatchGCN(a, x, labels, lmask, total, h, c, w1, w2, seed=123)
+    first = eng.train_step().cpu().tolist()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        eng.train_step()
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    # the same first step on the host: same inputs, weights and Philox masks
+    rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+    sup = (np.stack([rows, ci], 1), v, (n, n))
+    xr, xc = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(f, dtype=np.int32), indexing="ij")
+    xt = (np.stack([xr.ravel(), xc.ravel()], 1), x.cpu().numpy().ravel().copy(), (n, f))
+    orc = omodel.TwoLayerOracle("gcn", xt, [sup], [[w1.cpu().numpy()], [w2.cpu().numpy()]], lr=0.01, weight_decay=5e-4)
+    m1 = oracle.bernoulli_mask(n * f, 0.5, 123 * 2 + 1, 1 << 44)
+    m2 = oracle.bernoulli_mask(n * h, 0.5, 123 * 2 + 2, 1 << 44)
+    reg = 0.5 * 5e-4 * float((w1.double() ** 2).sum().item())
+    yl, ml = labels.cpu().numpy(), lmask.cpu().numpy()
+    t0 = time.perf_counter()
+    loss, acc = orc.train_step(yl, ml, m1, m2, 0.5)
+    cpu_s = time.perf_counter() - t0
+    return {
+        "instance": "RMAT scale %d (2^%d nodes, nnz %d), F=%d, hidden %d, %d classes, dropout 0.5, one full-batch "
+                    "training epoch (forward, masked loss, backward, Adam)" % (scale, scale, a.nnz, f, h, c),
+        "cpu_ms": cpu_s * 1e3, "cores": 1, "kind": "port",
+        "what": "oracle.model.TwoLayerOracle.train_step: sparse products in tuple order as TensorFlow's CPU kernel "
+                "walks them, dense products as plain fp32 loops, one thread; mask generation not timed",
+        "gpu_ms": gpu_ms, "gpu_what": "gcn_amd.engine.FullBatchGCN.train_step on the same instance (launch-bound at "
+                                      "this size), mean of %d steps" % reps,
+        "first_step_loss_cpu": loss, "first_step_loss_gpu": first[0] + reg,
+        "first_step_loss_agrees": bool(abs(loss - (first[0] + reg)) <= 1e-5 * abs(loss)),
+    }
+
+
+def one_gpu_denominator(args, shard_scale):
+    """The single-GPU run a multi-GPU line's speed-up refers to: the same shard shape
+    (2^shard_scale rows, same degree, widths and arithmetic) alone on one GPU,
+    `python bench.py --scale S --edge-factor E`.  Its recorded line is looked up
+    under profiles/ (newest round first); nothing is measured here."""
+    want = "RMAT scale %d (2^%d nodes), avg degree %d, F=%d, hidden %d, %d classes" % (
+        shard_scale, shard_scale, 2 * args.edge_factor, args.features, args.hidden, args.classes)
+    out = {"command": "python bench.py --scale %d --edge-factor %d" % (shard_scale, args.edge_factor),
+           "workload": want, "recorded": None}
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted((f for f in os.listdir(pdir) if f.endswith(".json") and "bench_line" in f), reverse=True)
+    except OSError:
+        names = []
+    for name in names:
+        try:
+            with open(os.path.join(pdir, name)) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        cfg = rec.get("config", {}) if isinstance(rec, dict) else {}
+        if rec.get("n_gpus") == 1 and str(cfg.get("workload", "")).startswith(want) and \
+                cfg.get("order", "reference") == args.order and \
+                cfg.get("dense_arith", "f32") == args.dense_arith and rec.get("value"):
+            out["recorded"] = {"file": "profiles/" + name, "value": rec["value"], "unit": rec.get("unit"),
+                               "ms_per_step": rec.get("ms_per_step")}
+            break
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=0, help="log2 of the node count (default 24 + log2 gpus)")
-    ap.add_argument("--edge-factor", type=int, default=8, help="undirected edges per node (avg degree = 2x)")
+    ap.add_argument("--edge-factor", type=int, default=0,
+                    help="undirected edges per node (avg degree = 2x).  Default: 8 on one GPU (RMAT 2^24, degree 16: "
+                         "the single-GPU headline configuration), 16 on several (degree 32: RMAT 2^27 at 8 GPUs, the "
+                         "row-partitioned configuration)")
     ap.add_argument("--features", type=int, default=256)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--classes", type=int, default=16)
@@ -122,6 +213,13 @@ def main():
                          "(gcnx_halo_allgather_f32, default) or through torch.distributed")
     ap.add_argument("--label-every", type=int, default=100,
                     help="every how many-th node is labelled (default 100: 1 %% of the nodes)")
+    ap.add_argument("--f32-side-steps", type=int, default=3,
+                    help="one GPU, split_bf16 arithmetic: after the timed steps, build the engine once more with every "
+                         "dense product on exact fp32 MFMA chains and time this many steps as a side measurement "
+                         "(ms_per_step_f32_chains; 0 = skip)")
+    ap.add_argument("--cpu-epoch-scale", type=int, default=18,
+                    help="one GPU: log2 of the node count of the small RMAT instance on which the oracle's full "
+                         "training epoch is timed on the host next to the GPU's (cpu_baseline.epoch; 0 = skip)")
     ap.add_argument("--dense-side-steps", type=int, default=3,
                     help="after the timed steps, time this many steps with the dense backward products as a side "
                          "measurement (ms_per_step_dense_gradients; 0 = skip)")
@@ -131,6 +229,8 @@ def main():
     args = ap.parse_args()
     if args.label_every < 1:
         raise SystemExit("--label-every must be at least 1")
+    if args.edge_factor <= 0:
+        args.edge_factor = 8 if args.gpus == 1 else 16
 
     t_start = time.time()
     import torch
@@ -248,10 +348,13 @@ def main():
             comm = None
         else:
             note("C-ABI communicator up, self-check passed")
-    model = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
-                       row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
-                       slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
-                       sparse_loss_gradient=not args.dense_loss_gradient)
+    def make_engine():
+        return engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
+                          row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
+                          slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
+                          sparse_loss_gradient=not args.dense_loss_gradient)
+
+    model = make_engine()
     nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
                           device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -353,6 +456,36 @@ def main():
             dist.all_reduce(td, op=dist.ReduceOp.MAX, group=group)
         dense_ms = float(td.item()) / args.dense_side_steps * 1e3
 
+    # Second side measurement (one GPU): the same step with every dense product and the
+    # factored SpMM's row-forming on exact fp32 MFMA chains instead of the exactly split
+    # bf16 operands -- a second engine built under that arithmetic (its set-up asks the
+    # library which fused kernels that arithmetic serves), timed with and without the
+    # backward shortcuts.
+    f32_ms = f32_dense_ms = None
+    if world == 1 and args.dense_arith == "split_bf16" and args.f32_side_steps > 0:
+        ops.dense_arith(1)
+        try:
+            model_f = make_engine()
+
+            def timed_steps(m, k):
+                m.train_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    m.train_step()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / k * 1e3
+
+            f32_ms = timed_steps(model_f, args.f32_side_steps)
+            if not args.dense_loss_gradient and model_f.at_dz is not None:
+                model_f.use_dense_gradients()
+                f32_dense_ms = timed_steps(model_f, args.f32_side_steps)
+            del model_f
+        finally:
+            ops.dense_arith(0)
+        torch.cuda.empty_cache()
+        note("fp32-chain side measurement done")
+
     if rank == 0:
         # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
         units = model.spmm_units_per_step(nnz_global, nnz_dz_global, nnz_bwd_global)
@@ -387,6 +520,14 @@ def main():
             },
             "epoch_ms": dt / args.steps * 1e3,
             "ms_per_step_dense_gradients": dense_ms,
+            "ms_per_step_f32_chains": f32_ms,
+            "ms_per_step_f32_chains_dense_gradients": f32_dense_ms,
+            "side_measurements": "ms_per_step is the timed region (dense_arith as in config; backward products over "
+                                 "the nonzeros and rows the masked loss can reach).  ms_per_step_dense_gradients: the "
+                                 "same engine with every backward product over every nonzero and row, as the "
+                                 "reference multiplies.  ms_per_step_f32_chains(_dense_gradients): a second engine with "
+                                 "every dense product on exact fp32 MFMA chains (--dense-arith f32).  All after the "
+                                 "timed region, a few steps each, not part of value.",
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,
         }
@@ -451,6 +592,15 @@ def main():
             except Exception as exc:  # the baseline is a side measurement; never lose the line
                 result["cpu_baseline"] = {"value": None, "unit": "nnz*F/s", "cores": 0, "kind": "port",
                                           "sample": "failed: %r" % (exc,)}
+            if args.cpu_epoch_scale and "cpu_baseline" in result and result["cpu_baseline"].get("value"):
+                try:
+                    result["cpu_baseline"]["epoch"] = cpu_epoch_baseline(args.cpu_epoch_scale, args, dev)
+                except Exception as exc:
+                    result["cpu_baseline"]["epoch"] = {"cpu_ms": None, "failed": repr(exc)}
+        if world > 1:
+            # what the node-level speed-up of this configuration is measured against: the
+            # same per-GPU shard shape (2^24 rows, this degree) run alone on one GPU
+            result["one_gpu_denominator"] = one_gpu_denominator(args, scale - int(math.log2(world)))
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier(group=group)

@@ -534,7 +534,7 @@ __device__ __forceinline__ unsigned lds_offset(const void *p) {
 // instructions and rewrites it before every use of its own, so the write here needs no clobber entry.
 __device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_base)
-               : "memory");
+               : "memory");   // M0 is a reserved register: the compiler sets it before each use of its own
 }
 __device__ __forceinline__ void block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // 16-byte unit of (row r, half hf) inside a split tile of 32-byte rows: the XOR puts

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
                    "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                    "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off"
                    ::"v"(drow), "v"(drow + 4), "v"(grow), "s"(dst)
-                   : "memory");
+                   : "memory", "scc");   // s_add_u32 writes SCC (M0 is reserved: the compiler sets it before each use of its own)
     };
     int cols, cols_n = 0;
     float vals, vals_n = 0.0f;

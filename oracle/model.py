@@ -155,3 +155,70 @@ def train(oracle, y_train, train_mask, y_val, val_mask, y_test, test_mask, mask_
             break
     tloss, tacc = oracle.evaluate(y_test, test_mask)
     return dict(trace=trace, test_cost=tloss, test_acc=tacc, epochs_run=len(trace))
+
+
+def dense_gcn_step_f64(a_hat, x, w1, w2, labels, mask, m1, m2, keep):
+    """One forward + backward pass of the two-layer GCN with DENSE features
+    (gcn/layers.py:203-226 with sparse_inputs=False, gcn/metrics.py:4-11 and the
+    gradients TensorFlow derives from them, gcn/models.py:58) evaluated in fp64,
+    together with the yardstick fp32 parity is measured against: for every
+    result a bound ``M`` on the summed magnitude of the terms it is made of.
+    A product C = A B of inexact operands gets M(C) = M(A) M(B) (a leaf has
+    M = |value|); relu and dropout pass M through (a relu that would zero an
+    element does not zero its M: the fp32 value may sit on the other side of
+    zero by a rounding error).  Where the relu gate of the backward pass is
+    itself within rounding of zero (|A P1| <= 1e-5 M), a flipped gate changes the
+    element by its full size; those elements carry that size / 1e-5 in M, so that
+    a bound of 1e-5 M admits the flip.
+
+    ``a_hat``: scipy CSR whose values are the fp32 values of the matrix;
+    ``m1`` [N, F] / ``m2`` [N, H]: uint8 dropout masks (None with keep = 1);
+    weight decay is not included (it is applied inside Adam).  Returns a dict
+    name -> (value, M) for "logits", "xent", "g1", "g2"."""
+    a = a_hat.astype(np.float64).tocsr()
+    a_abs = abs(a)
+    at, at_abs = a.T.tocsr(), a_abs.T.tocsr()
+    x, w1, w2 = (np.asarray(v, dtype=np.float64) for v in (x, w1, w2))
+    y = np.asarray(labels, dtype=np.float64)
+    msk = np.asarray(mask, dtype=np.float64)
+    total = msk.sum()
+    n = x.shape[0]
+    if keep < 1.0:
+        k1 = np.asarray(m1).reshape(x.shape) != 0
+        xd = np.where(k1, x / keep, 0.0)
+    else:
+        xd = x
+    p1, mp1 = xd @ w1, np.abs(xd) @ np.abs(w1)
+    ap, map_ = a @ p1, a_abs @ mp1
+    h = np.maximum(ap, 0.0)
+    if keep < 1.0:
+        k2 = np.asarray(m2).reshape(h.shape) != 0
+        hd, mhd = np.where(k2, h / keep, 0.0), np.where(k2, map_ / keep, 0.0)
+    else:
+        k2 = np.ones(h.shape, dtype=bool)
+        hd, mhd = h, map_
+    p2, mp2 = hd @ w2, mhd @ np.abs(w2)
+    z, mz = a @ p2, a_abs @ mp2
+    zs = z - z.max(axis=1, keepdims=True)
+    e = np.exp(zs)
+    p = e / e.sum(axis=1, keepdims=True)
+    logp = zs - np.log(e.sum(axis=1, keepdims=True))
+    row_w = (msk / total)[:, None]
+    mz_row = mz.max(axis=1, keepdims=True)
+    xent = float(-(row_w * y * logp).sum())
+    m_xent = float((row_w[:, 0] * (np.abs((y * logp).sum(axis=1)) + 2.0 * mz_row[:, 0])).sum())
+    dz = row_w * (p - y * y.sum(axis=1, keepdims=True))
+    mdz = row_w * (np.abs(p - y) + 2.0 * p * mz_row)
+    dp2, mdp2 = at @ dz, at_abs @ mdz
+    g2, mg2 = hd.T @ dp2, mhd.T @ mdp2
+    dhd, mdhd = dp2 @ w2.T, mdp2 @ np.abs(w2).T
+    gate = k2 & (ap > 0)
+    dap = np.where(gate, dhd / keep, 0.0)
+    mdap = np.where(k2, mdhd / keep, 0.0)
+    unclear = k2 & (np.abs(ap) <= 1e-5 * map_)
+    mdap = mdap + np.where(unclear, np.abs(dhd) / keep / 1e-5, 0.0)
+    dp1, mdp1 = at @ dap, at_abs @ mdap
+    g1, mg1 = xd.T @ dp1, np.abs(xd).T @ mdp1
+    assert z.shape[0] == n
+    return {"logits": (z, mz), "xent": (xent, m_xent), "g1": (g1, mg1), "g2": (g2, mg2),
+            "unclear_gates": int(unclear.sum())}

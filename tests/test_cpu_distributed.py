@@ -1,4 +1,4 @@
-"""world_size-2 tests of the row-partitioned engine on the gloo backend (CPU).
+"""world_size 2, 3, 4 and 8 tests of the row-partitioned engine on the gloo backend (CPU).
 The kernels are answered by the oracle (tests/helpers.OracleKernels); what is
 under test is the partition, the halo plan and the slabbed halo all-to-all of the dense
 operand, the all-reduce of weight gradients / loss, and the rule that dropout masks depend on
@@ -93,7 +93,9 @@ def _free_port():
     # halo rows of the hidden-width products recomputed by the GPU that needs them
     (2, 16, "recompute", 32, 5), (4, 8, "recompute", 64, 5),
     # ... and the backward SpMM with the factored operand over local + halo rows
-    (2, 16, "recompute", 64, 16)])
+    (2, 16, "recompute", 64, 16),
+    # eight ranks, the count the row-partitioned RMAT-27 configuration runs at
+    (8, 8, "exchange", 16, 5), (8, 16, "recompute", 64, 16)])
 def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden, classes):
     out = str(tmp_path)
     _run(0, 1, 0, None, out, "auto", hidden, classes=classes)
@@ -114,7 +116,8 @@ def test_ranks_match_one_rank(tmp_path, world, slab, halo_mode, hidden, classes)
     np.testing.assert_allclose(z, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
 
 
-@pytest.mark.parametrize("world,hidden,classes,dropout", [(2, 64, 16, 0.5), (2, 32, 5, 0.5), (4, 64, 16, 0.0)])
+@pytest.mark.parametrize("world,hidden,classes,dropout", [(2, 64, 16, 0.5), (2, 32, 5, 0.5), (4, 64, 16, 0.0),
+                                                          (8, 64, 16, 0.5)])
 def test_few_labels_ranks_match_one_rank(tmp_path, world, hidden, classes, dropout):
     """Few labelled nodes: the backward products run over the rows and columns the
     labelled nodes reach (sub-matrices, rows formed next to each other, the weight

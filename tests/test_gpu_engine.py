@@ -107,40 +107,70 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     else:
         assert eng.at_dz is None and eng.at_wide is None
         assert eng.loss_gradient_nnz() == a.nnz == eng.backward_nnz()
+    import scipy.sparse as sp
     rp, ci, v = a.row_ptr.cpu().numpy(), a.col_idx.cpu().numpy(), a.val.cpu().numpy()
     rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
     sup = (np.stack([rows, ci], 1), v, (n, n))
+    a_sp = sp.csr_matrix((v, ci, rp), shape=(n, n))
     orc = omodel.TwoLayerOracle("gcn", _dense_tuple(x), [sup], [[w1], [w2]], lr=0.01, weight_decay=5e-4)
-    unclear = {}
+    lr, wd = 0.01, 5e-4
+    N = lambda t: t.detach().cpu().numpy().copy()
+    # per element: how far the engine's weights may be from the fp32 oracle's, given how
+    # far the gradients that entered Adam were apart (see below)
+    slack = [np.zeros_like(w1), np.zeros_like(w2)]
+    eps_hist = [[], []]
     for step in (1, 2, 3):
         off = step * (1 << 44)
         m1 = env["oracle"].bernoulli_mask(n * f, 0.5, 123 * 2 + 1, off)
         m2 = env["oracle"].bernoulli_mask(n * hidden, 0.5, 123 * 2 + 2, off)
+        # fp32 oracle (TensorFlow order), run at its own weights
         logits, cache = orc.forward(m1, m2, 0.5)
         xent, grad = env["oracle"].masked_softmax_xent(logits, labels, lmask)
         acc = env["oracle"].masked_accuracy(logits, labels, lmask)
         grads = orc.backward(cache, grad)
-        g_ref = [grads[0][0] - np.float32(5e-4) * orc.w[0][0], grads[1][0]]    # without the weight-decay term
+        g_ref = [grads[0][0] - np.float32(wd) * orc.w[0][0], grads[1][0]]    # without the weight-decay term
         orc.adam(grads)
+        # fp64 evaluation of the same step AT THE ENGINE'S weights, with the size of
+        # the summed terms of every result: the yardstick of the 1e-5 bar
+        before = [(N(eng.w1), N(eng.m1), N(eng.v1)), (N(eng.w2), N(eng.m2), N(eng.v2))]
+        y64 = omodel.dense_gcn_step_f64(a_sp, x, before[0][0], before[1][0], labels, lmask,
+                                        m1.reshape(n, f), m2.reshape(n, hidden), 0.5)
         got = eng.train_step().cpu().numpy()
-        for g_gpu, g_want in zip((eng.g1, eng.g2), g_ref):
-            assert np.abs(g_gpu.cpu().numpy() - g_want).max() <= 2e-5 * np.abs(g_want).max()
+        g_gpu = [N(eng.g1), N(eng.g2)]
+        # (1) logits, loss and both gradients within 1e-5 of the summed terms, element by
+        # element, and within 1e-5 of the largest element
+        assert_close_to_f64(N(eng.z), *y64["logits"], what="logits, step %d" % step)
+        assert abs(got[0] - y64["xent"][0]) <= 1e-5 * y64["xent"][1]
+        for name, g in zip(("g1", "g2"), g_gpu):
+            assert_close_to_f64(g, *y64[name], what="%s, step %d" % (name, step))
+            assert np.abs(g - y64[name][0]).max() <= 1e-5 * np.abs(y64[name][0]).max(), (name, step)
+        assert np.abs(N(eng.z) - y64["logits"][0]).max() <= 1e-5 * np.abs(y64["logits"][0]).max()
+        # ... and against the fp32 oracle's own loss and accuracy
         assert abs(got[0] - xent) <= 1e-5 * abs(xent) + 1e-6, (step, got[0], xent)
         assert abs(got[1] - acc) <= 1e-6
-        assert np.abs(eng.z.cpu().numpy() - logits).max() <= 2e-5 * np.abs(logits).max()
-        # an Adam step moves every weight by about lr whatever the gradient's size, so
-        # with the other association a near-zero gradient may round the other way
-        wtol = 2e-6 if order == "reference" else 2e-4
-        for w_gpu, w_ref, g_want in ((eng.w1, orc.w[0][0], grads[0][0]), (eng.w2, orc.w[1][0], grads[1][0])):
-            err = np.abs(w_gpu.cpu().numpy() - w_ref)
-            # entries whose gradient is within rounding of zero may step the other
-            # way (by up to 2 lr per step); they are bounded, the rest is compared
-            key = id(w_gpu)
-            unclear[key] = unclear.get(key, False) | (np.abs(g_want) <= 1e-3 * np.abs(g_want).max())
-            clear = ~unclear[key]
-            assert clear.mean() > 0.9
-            assert err[clear].max() <= 1e-5 * np.abs(w_ref).max() + wtol
-            assert err.max() <= 2 * 0.01 * step + 1e-6
+        # (2) the update rule by itself: the oracle's Adam applied to the engine's own
+        # state and gradient reproduces the engine's new weights to rounding
+        # (what enters Adam is the gradient plus the weight-decay term of layer 1)
+        adam_in = [(g_gpu[0] + np.float32(wd) * before[0][0]).astype(np.float32), g_gpu[1]]
+        for (w0, m0, v0), ge, w_new in zip(before, adam_in, (eng.w1, eng.w2)):
+            env["oracle"].adam_step(w0, ge, m0, v0, lr, step)
+            assert np.abs(N(w_new) - w0).max() <= 4e-7 * np.abs(w0).max() + lr * 1e-6
+        # (3) end to end against the fp32 oracle.  Adam divides the gradient by its own
+        # size: an element whose gradient entered relatively off by e moves off by up to
+        # ~2 lr min(1, e) in this and in each later step, whatever its size.  e is taken
+        # from the gradients that were actually compared above, element by element, so the
+        # slack is ~1e-7 where the gradients agree to rounding and grows only where the
+        # gradient is itself within rounding of zero (nothing is masked out).
+        for i, (g, want) in enumerate(zip(adam_in, (grads[0][0], grads[1][0]))):
+            e = np.minimum(1.0, np.abs(g - want) / (np.abs(want) + 1e-30))
+            eps_hist[i].append(e)
+            slack[i] = slack[i] + 2.0 * lr * sum(eps_hist[i])
+        for i, (w_gpu, w_ref) in enumerate(((eng.w1, orc.w[0][0]), (eng.w2, orc.w[1][0]))):
+            err = np.abs(N(w_gpu) - w_ref)
+            tol = 1e-5 * np.abs(w_ref) + 4e-7 * step + slack[i]
+            assert (err <= tol).all(), (i, step, float((err / tol).max()))
+            # the slack is no loophole: nine elements in ten are held to a small fraction of a step
+            assert np.median(slack[i]) <= 0.02 * lr and np.quantile(slack[i], 0.9) <= 0.2 * lr
     ev = eng.evaluate().cpu().numpy()
     logits, _ = orc.forward()
     xent, _ = env["oracle"].masked_softmax_xent(logits, labels, lmask, want_grad=False)
@@ -212,6 +242,62 @@ def test_spmm_properties_at_scale(env, scale):
     # transpose of a symmetric matrix reproduces it bit for bit
     t = a.transpose()
     assert torch.equal(t.row_ptr, a.row_ptr) and torch.equal(t.col_idx, a.col_idx) and torch.equal(t.val, a.val)
+
+
+def test_degree32_shard_at_scale(env):
+    """The per-GPU shard of the row-partitioned RMAT-27 configuration: 2^24 rows at
+    average degree 32 (edge factor 16, 537 M nonzeros).  Sampled rows of the
+    hidden-width and of the class-width product against an fp64 gather on the
+    device (hub rows included), run-to-run reproducibility, then one engine step
+    with the benchmark's widths: finite loss, and the class-width logits of sampled
+    rows consistent with the stored P2 to the 1e-5 bar."""
+    torch, dev, ops = env["torch"], env["dev"], env["ops"]
+    torch.cuda.empty_cache()
+    scale, ef = 24, 16
+    a = env["rmat"].rmat_ahat(scale, ef, 123, dev)
+    n = a.n_rows
+    assert n == 1 << 24 and 5.2e8 < a.nnz < 5.6e8
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    deg = (a.row_ptr[1:] - a.row_ptr[:-1])
+    hubs = torch.topk(deg, 6).indices.tolist()
+    rows = hubs + torch.randint(0, n, (150,), generator=torch.Generator().manual_seed(4)).tolist() + [0, n - 1]
+
+    def check_rows(out, b, what):
+        for r in rows:
+            s, e = int(a.row_ptr[r]), int(a.row_ptr[r + 1])
+            terms = a.val[s:e].double()[:, None] * b[a.col_idx[s:e].long()].double()
+            ref, mag = terms.sum(0), terms.abs().sum(0)
+            err = (out[r].double() - ref).abs()
+            assert bool((err <= 1e-5 * mag + 1e-30).all()), (what, r, e - s, float(err.max()))
+
+    for width in (256, 16):
+        b = torch.rand((n, width), device=dev, generator=g) * 2 - 1
+        out = ops.spmm(a, b)
+        assert torch.equal(out, ops.spmm(a, b))
+        check_rows(out, b, "width %d" % width)
+        del b, out
+    # one training step of the benchmark's model on this shard
+    x = ops.philox_uniform((n, 256), -1.0, 1.0, 124, 0, dev)
+    w1 = ops.philox_uniform((256, 256), -0.1, 0.1, 125, 0, dev)
+    w2 = ops.philox_uniform((256, 16), -0.15, 0.15, 125, 1 << 40, dev)
+    cls = ops.philox_uniform((n,), 0.0, 16.0, 126, 0, dev).to(torch.int64).clamp_(0, 15)
+    labels = torch.zeros((n, 16), device=dev)
+    labels.scatter_(1, cls.view(-1, 1), 1.0)
+    lmask = (torch.arange(n, device=dev) % 100 == 0).to(torch.uint8)
+    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123)
+    assert eng.factored_bwd and eng.at_wide is not None and eng.at_wide.nnz < a.nnz
+    w1_before = eng.w1.clone()
+    out = eng.train_step().cpu().numpy()
+    assert np.isfinite(out).all() and 1.0 < out[0] < 10.0 and 0.0 <= out[1] <= 1.0
+    check_rows(eng.z, eng.p2, "logits = A_hat P2")
+    assert bool(torch.isfinite(eng.w1).all()) and bool(torch.isfinite(eng.g1).all()) and bool(torch.isfinite(eng.g2).all())
+    moved = (eng.w1 - w1_before).abs().max().item()
+    assert 0.0 < moved <= 0.0101                    # Adam's first step moves a weight by at most lr
+    out2 = eng.train_step().cpu().numpy()
+    assert np.isfinite(out2).all()
+    del eng
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("halo_mode,features,hidden,order", [

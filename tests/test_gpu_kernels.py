@@ -1138,3 +1138,65 @@ def test_gather_hint_changes_no_result(env, chunk):
         assert torch.equal(got, ref), thr
     a.clear_gather_hint()
     assert torch.equal(ops.spmm(a, b, relu=True), ref)
+
+
+@pytest.mark.parametrize("n_sup,width,f64", [(1, 16, True), (2, 7, True), (4, 16, True), (4, 6, False), (3, 64, True)])
+def test_interleaved_supports_equal_sum_of_products(env, n_sup, width, f64):
+    """The multi-support sum of the reference, add_n over A_i . P_i
+    (gcn/layers.py:213-221), as this library forms it: gcnx_coo_interleave_supports
+    merges the supports' tuples into one over the columns col * S + i (checked entry
+    by entry), and one SpMM of the merged matrix with P_cat viewed as [N * S, width]
+    must equal the sum of the S tuple-order products of the oracle (one of the
+    supports is the identity, as T_0 is; one has an empty row block)."""
+    import ctypes as C
+    from gcn_amd import _lib
+    from gcn_amd.sparse import _ptr, _stream
+    torch, dev, orc = env["torch"], env["dev"], env["oracle"]
+    rng = np.random.RandomState(100 * n_sup + width)
+    n = 700
+    tuples = []
+    for i in range(n_sup):
+        if i == 0:
+            r = c = np.arange(n, dtype=np.int32)
+            v = np.ones(n)
+        else:
+            r, c, v = random_coo(rng, n, n, 2000 * (i + 1), empty_rows=list(range(100 * i, 100 * i + 40)))
+        v = v.astype(np.float64 if f64 else np.float32)
+        order = rng.permutation(len(v))                     # tuples arrive unsorted (gcn/utils.py:93-109)
+        tuples.append((np.ascontiguousarray(np.stack([r[order], c[order]], 1).astype(np.int32)), v[order]))
+    coords = [torch.from_numpy(t[0]).to(dev) for t in tuples]
+    vals = [torch.from_numpy(t[1]).to(dev) for t in tuples]
+    nnz = [len(t[1]) for t in tuples]
+    total = sum(nnz)
+    out_row = torch.empty(total, dtype=torch.int32, device=dev)
+    out_col = torch.empty(total, dtype=torch.int32, device=dev)
+    out_val = torch.empty(total, dtype=torch.float64 if f64 else torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.gcnx_coo_interleave_supports(
+        n_sup, (C.c_int64 * n_sup)(*nnz), (C.c_void_p * n_sup)(*[c.data_ptr() for c in coords]),
+        (C.c_void_p * n_sup)(*[c.data_ptr() + 4 for c in coords]), 2,
+        (C.c_void_p * n_sup)(*[v.data_ptr() for v in vals]), 1 if f64 else 0, _ptr(out_row), _ptr(out_col),
+        _ptr(out_val), _stream()))
+    # entry by entry: support i's k-th tuple lands at offset(i) + k with its column moved to col * S + i
+    want_row = np.concatenate([t[0][:, 0] for t in tuples])
+    want_col = np.concatenate([t[0][:, 1].astype(np.int64) * n_sup + i for i, t in enumerate(tuples)]).astype(np.int32)
+    want_val = np.concatenate([t[1] for t in tuples])
+    assert np.array_equal(out_row.cpu().numpy(), want_row)
+    assert np.array_equal(out_col.cpu().numpy(), want_col)
+    assert np.array_equal(out_val.cpu().numpy().view(np.uint8), want_val.view(np.uint8))
+    merged = env["sparse"].Csr.from_coo(out_row, out_col, out_val, (n, n * n_sup), dev)
+    p = rng.standard_normal((n, n_sup * width)).astype(np.float32)          # P_cat = x . [W_0 | ... | W_S-1]
+    got = env["ops"].spmm(merged, torch.from_numpy(p).to(dev).view(n * n_sup, width)).cpu().numpy()
+    ref32 = np.zeros((n, width), dtype=np.float32)
+    ref64 = np.zeros((n, width))
+    mag = np.zeros((n, width))
+    for i, (cd, v) in enumerate(tuples):
+        pi = np.ascontiguousarray(p[:, i * width:(i + 1) * width])
+        v32 = v.astype(np.float32)
+        ref32 += orc.spmm_coo(cd[:, 0].copy(), cd[:, 1].copy(), v32, pi, n)   # tf.add_n of the supports' products
+        rp, ci, cv, _ = orc.csr_from_coo(cd[:, 0].copy(), cd[:, 1].copy(), v32, (n, n))
+        r64, m64 = orc.spmm_csr_f64(rp, ci, cv, pi)
+        ref64 += r64
+        mag += m64
+    assert_close_to_f64(got, ref64, mag, what="merged supports S=%d w=%d" % (n_sup, width))
+    assert rel_maxnorm(got, ref32) <= RTOL
