@@ -331,6 +331,8 @@ def main():
         from gcn_amd.comm import RcclComm
         ok, why = 1, ""
         try:
+            # (the constructor agrees among the ranks before it creates anything: if RCCL
+            # cannot be loaded or the id cannot be made anywhere, it raises on every rank)
             comm = RcclComm(group, world, rank, dev)
             # self-check before anything is timed: known answers through the same entry points
             good, why = comm.self_check()
@@ -358,6 +360,11 @@ def main():
     nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
                           device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
+        # the engine's set-up went through the library's communicator: nothing of it may
+        # still be in flight when torch.distributed's communicator carries this sum (two
+        # RCCL communicators of one process never run side by side here; every
+        # torch.distributed collective below is bracketed by a device synchronisation)
+        torch.cuda.synchronize()
         dist.all_reduce(nnz_dz, group=group)
     nnz_dz_global, nnz_bwd_global = (int(v) for v in nnz_dz.tolist())
     torch.cuda.synchronize()

@@ -32,17 +32,32 @@ class RcclComm(object):
         to broadcast the id).  Binds the communicator to ``device``."""
         import torch.distributed as dist
         lib = _lib.load()
-        if not lib.gcnx_comm_available():
-            raise RuntimeError("RCCL could not be loaded by libgcnhip.so; no multi-GPU data path")
         self.world, self.rank = int(world), int(rank)
         self.device = torch.device(device)
+        self._comm = None
+        # Every rank walks through the same collectives whatever fails locally, and
+        # all of them learn the outcome before the communicator is created: a rank
+        # that raised early would leave the others waiting in the broadcast or in
+        # ncclCommInitRank.
+        ok, why = 1, ""
+        if not lib.gcnx_comm_available():
+            ok, why = 0, "RCCL could not be loaded by libgcnhip.so on rank %d" % self.rank
         ident = (C.c_char * _lib.COMM_ID_BYTES)()
         with torch.cuda.device(self.device):
-            if self.rank == 0:
-                _lib.check(lib.gcnx_comm_unique_id(ident))
-            box = [bytes(ident.raw) if self.rank == 0 else None]
+            if self.rank == 0 and ok:
+                rc = lib.gcnx_comm_unique_id(ident)
+                if rc != 0:
+                    ok, why = 0, "gcnx_comm_unique_id failed on rank 0: %s" % (lib.gcnx_last_error() or b"").decode()
+            box = [(ok, why, bytes(ident.raw)) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            ident = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(box[0])
+            if not box[0][0]:
+                ok, why = 0, why or box[0][1]
+            backend = str(dist.get_backend(group))
+            agree = torch.tensor([ok], dtype=torch.int32, device=self.device if "nccl" in backend else "cpu")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
+            if int(agree.item()) == 0:
+                raise RuntimeError(why or "a peer cannot create the RCCL communicator; no multi-GPU data path")
+            ident = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(box[0][2])
             handle = C.c_void_p(0)
             _lib.check(lib.gcnx_comm_create(self.world, self.rank, ident, C.byref(handle)))
         self._comm = handle

@@ -17,6 +17,7 @@
 // (slot 0: the row began in an earlier chunk; slot 1: it begins here and runs
 // on); spmm_fixup_kernel adds them in chunk order and applies the epilogue, so
 // the result does not depend on scheduling.
+#include <atomic>
 #include <mutex>
 
 #include "gcnx_common.h"
@@ -1176,8 +1177,11 @@ extern "C" int gcnx_spmm_chunk_nnz(void) { return kChunkUnit; }
 
 extern "C" int64_t gcnx_spmm_num_chunks(int64_t nnz) { return nnz <= 0 ? 0 : ceil_div(nnz, kChunkUnit); }
 
+static void static_scratch_warm();
+
 extern "C" int gcnx_spmm_chunk_table(const gcnx_csr *a, int32_t *chunk_row, void *stream) {
   GCNX_REQUIRE(a && chunk_row, GCNX_ERR_INVALID_ARG, "chunk_table: null argument");
+  static_scratch_warm();
   GCNX_REQUIRE(a->n_rows >= 0 && a->nnz >= 0 && a->n_rows < INT32_MAX, GCNX_ERR_INVALID_ARG,
                "chunk_table: bad shape");
   const int64_t n_chunks = gcnx_spmm_num_chunks(a->nnz);
@@ -1412,24 +1416,42 @@ static __device__ __align__(256) unsigned char scratch[GCNX_SPMM_STATIC_SCRATCH_
 namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
-void *g_scratch_ptr[kMaxDevices] = {};   // per device, written once under the mutex
+// per device; published once (under the mutex) and read without it afterwards
+std::atomic<void *> g_scratch_ptr[kMaxDevices];
 
-// Device address of `scratch` on the current device (looked up on first use).
+// Device address of `scratch` on the current device.  The first call on a device
+// looks it up (hipGetSymbolAddress loads the code object and maps the array: the
+// one moment the runtime may allocate, so it must not fall into a stream
+// capture -- gcnx_spmm_chunk_table, which every matrix needs before its first
+// product and which no caller runs under capture, makes that call); every later
+// call is one atomic load.
 int static_scratch(void **out) {
   int dev = -1;
   GCNX_CHECK_HIP(hipGetDevice(&dev));
   GCNX_REQUIRE(dev >= 0 && dev < kMaxDevices, GCNX_ERR_UNSUPPORTED, "spmm_static: device ordinal %d out of range", dev);
-  std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (!g_scratch_ptr[dev]) {
-    void *p = nullptr;
-    GCNX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-    GCNX_REQUIRE(p != nullptr, GCNX_ERR_HIP, "spmm_static: the scratch array has no address on device %d", dev);
-    g_scratch_ptr[dev] = p;
+  void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+    if (!p) {
+      GCNX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      GCNX_REQUIRE(p != nullptr, GCNX_ERR_HIP, "spmm_static: the scratch array has no address on device %d", dev);
+      g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
   }
-  *out = g_scratch_ptr[dev];
+  *out = p;
   return GCNX_OK;
 }
 }  // namespace
+
+// Called by gcnx_spmm_chunk_table (set-up, never under capture): resolves the
+// scratch array's address on the current device so that the no-allocation entry
+// point finds it published.  A failure here is not the chunk table's: it is
+// reported by gcnx_spmm_csr_static_f32 itself if that is ever called.
+static void static_scratch_warm() {
+  void *p = nullptr;
+  (void)static_scratch(&p);
+}
 
 extern "C" int gcnx_spmm_csr_static_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
                                         int64_t ldb, float *C, int64_t ldc, int32_t width, float alpha,

@@ -71,9 +71,9 @@ class FullBatchGCN(object):
         kernels serve it for these shapes.  ``comm`` (a gcn_amd.comm.RcclComm):
         the per-step exchanges and all-reduces go through the C ABI
         (gcnx_halo_allgather_f32 / gcnx_comm_allreduce_sum_f32, RCCL bound inside
-        libgcnhip.so) on the communicator's own stream; without it they go
-        through torch.distributed on ``group`` (the gloo rehearsal).  The
-        set-up exchanges of the halo plan always use ``group``.
+        libgcnhip.so) on the communicator's own stream, and so do the set-up
+        exchanges of the halo plan; without it everything goes through
+        torch.distributed on ``group`` (the gloo rehearsal).
         ``sparse_loss_gradient``: the rows of dZ outside the labelled set are
         exactly zero (the mask multiplies the per-row loss, gcn/metrics.py:4-11), so
         A_hat^T dZ is formed with the nonzeros of the labelled columns only, and
@@ -486,11 +486,33 @@ class FullBatchGCN(object):
     def _all_to_all_start(self, recv, send, recv_counts, send_counts):
         """Start the variable-size all-to-all (rows of dim 0) of already packed
         rows; returns a work handle or None when it has already completed."""
-        if self.comm is not None and recv.dim() == 2 and recv.element_size() == 4:
-            return self.comm.exchange_rows(recv, send, recv_counts, send_counts)
+        if self.comm is not None:
+            # everything that travels between the ranks once the library's communicator
+            # exists goes through it -- the set-up lists of the halo plan (row ranges,
+            # counts, requested row ids: 32- and 64-bit integers, moved as 32-bit words)
+            # as well as the per-step rows -- so that one communicator on one stream
+            # carries all traffic in issue order and torch.distributed's communicator
+            # is never in flight next to it
+            return self.comm.exchange_rows(self._as_words(recv), self._as_words(send), recv_counts, send_counts)
         import torch.distributed as dist
         return dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
                                       input_split_sizes=send_counts, group=self.group, async_op=True)
+
+    @staticmethod
+    def _as_words(t):
+        """``t`` (contiguous, rows along dim 0, 4- or 8-byte elements) viewed as a 2-D
+        matrix of 32-bit words with the same rows: the shape the C-ABI exchange moves."""
+        if not t.is_contiguous():
+            raise ValueError("exchange buffers must be contiguous")
+        rows = int(t.shape[0]) if t.dim() else 1
+        per_row = 1
+        for d in t.shape[1:]:
+            per_row *= int(d)
+        if t.element_size() == 4:
+            return t.view(rows, per_row)
+        if t.element_size() == 8:
+            return t.view(torch.int32).view(rows, 2 * per_row)
+        raise ValueError("exchange buffers hold 4- or 8-byte elements")
 
     def _all_to_all(self, recv, send, recv_counts, send_counts):
         work = self._all_to_all_start(recv, send, recv_counts, send_counts)

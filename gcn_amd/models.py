@@ -64,6 +64,7 @@ class Model(object):
         """Layers (created under the model's variable scope), the chain of their
         outputs, then loss, accuracy and the training op
         (reference gcn/models.py:38-58)."""
+        created_before = len(tf.get_collection(tf.GraphKeys.GLOBAL_VARIABLES))
         with tf.variable_scope(self.name):
             self._build()
         signal = self.inputs
@@ -72,8 +73,18 @@ class Model(object):
             signal = layer(signal)
             self.activations.append(signal)
         self.outputs = signal
-        # the variables of a model are those its layers created
+        # The variables of a model: the reference collects the global variables under the
+        # model's scope (gcn/models.py:50-51).  Here: those its layers created, plus any
+        # variable a subclass's _build created under the model's scope outside a layer
+        # (only variables born during this build, so that a second model of the same
+        # name does not pick up the first one's) -- the set that save / load see is the
+        # set the optimizer trains.
         self.vars = {v.name: v for layer in self.layers for v in layer.vars.values()}
+        in_scope = tf.get_collection(tf.GraphKeys.GLOBAL_VARIABLES, scope=self.name + "/")
+        born_here = set(id(v) for v in tf.get_collection(tf.GraphKeys.GLOBAL_VARIABLES)[created_before:])
+        for v in in_scope:
+            if id(v) in born_here:
+                self.vars.setdefault(v.name, v)
         self._loss()
         self._accuracy()
         self.opt_op = self.optimizer.minimize(self.loss)

@@ -399,8 +399,15 @@ def gemm_supports_a_dropout(trans_a, M, N, K):
 
 
 class _GemmFn(torch.autograd.Function):
+    """y = act(a @ b) with both gradients.  The arithmetic mode of the large
+    products (:func:`dense_arith`) is a per-thread setting of the library and
+    torch runs backward on a thread of its own, so the mode the forward product
+    ran under is kept with the node and put in force around the backward
+    products: forward and backward of one product use the same arithmetic."""
+
     @staticmethod
     def forward(ctx, a, b, relu):
+        ctx.arith = dense_arith()
         y = gemm(a, b, relu=relu)
         ctx.relu = relu
         if relu:
@@ -417,8 +424,12 @@ class _GemmFn(torch.autograd.Function):
             dy = relu_dropout_bwd(y, dy)
         else:
             a, b = ctx.saved_tensors
-        da = gemm(dy, b, trans_b=True) if ctx.needs_input_grad[0] else None
-        db = gemm(a, dy, trans_a=True) if ctx.needs_input_grad[1] else None
+        before = dense_arith(ctx.arith)
+        try:
+            da = gemm(dy, b, trans_b=True) if ctx.needs_input_grad[0] else None
+            db = gemm(a, dy, trans_a=True) if ctx.needs_input_grad[1] else None
+        finally:
+            dense_arith(before)
         return da, db, None
 
 

@@ -167,7 +167,15 @@ int gcnx_spmm_csr_f32(const gcnx_csr *a, const int32_t *chunk_row,
  * (every slot the fix-up pass reads is written by the main pass of the same
  * call), so the contents a previous call left behind are harmless; but all calls
  * on one GPU share the one array: calls that overlap on the same GPU (two
- * streams, two threads) race.  Same results, bit for bit, as gcnx_spmm_csr_f32. */
+ * streams, two threads) race.  Same results, bit for bit, as gcnx_spmm_csr_f32.
+ * The array's device address is looked up once per device, by the first
+ * gcnx_spmm_chunk_table call on that device (set-up: every matrix needs its
+ * chunk table before its first product, and nobody builds it under capture) or,
+ * failing that, by the first call of this entry point -- that one look-up loads
+ * the code object and may allocate inside the runtime, so a caller that records
+ * this entry point in a HIP graph makes one of those two calls on the device
+ * before the capture starts.  Every later call reads the published pointer
+ * (one atomic load, no lock). */
 #define GCNX_SPMM_STATIC_SCRATCH_BYTES (32u << 20)
 int gcnx_spmm_csr_static_f32(const gcnx_csr *a, const int32_t *chunk_row,
                              const float *B, int64_t ldb, float *C, int64_t ldc,

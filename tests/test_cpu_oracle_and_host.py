@@ -458,3 +458,41 @@ def test_loss_expression_splits_weight_decay_terms():
     plain = tf.train.AdamOptimizer(0.01).minimize(ce)
     assert plain.rest is ce and plain.decay == {}
     tf.reset_default_graph()
+
+
+def test_model_vars_include_variables_created_outside_layers():
+    """Model.vars is what save / load store (reference gcn/models.py:50-51 collects
+    the global variables under the model's scope): a subclass that creates a
+    variable in _build outside any layer gets it into vars; a second model of the
+    same name does not pick up the first one's variables."""
+    from gcn_amd import models, tfcompat as tf
+    from gcn_amd.train import define_flags
+    tf.reset_default_graph()
+    define_flags()
+    tf.app.flags.FLAGS._parse([])
+
+    class WithTemperature(models.GCN):
+        def _build(self):
+            super(WithTemperature, self)._build()
+            self.temperature = tf.Variable(tf.ones([1]), name="temperature")
+
+    def placeholders():
+        return {"support": [tf.sparse_placeholder(tf.float32)],
+                "features": tf.sparse_placeholder(tf.float32, shape=(10, 5)),
+                "labels": tf.placeholder(tf.float32, shape=(None, 3)),
+                "labels_mask": tf.placeholder(tf.int32),
+                "dropout": tf.placeholder_with_default(0., shape=()),
+                "num_features_nonzero": tf.placeholder(tf.int32)}
+
+    m1 = WithTemperature(placeholders(), input_dim=5, name="gcnt")
+    names = sorted(m1.vars)
+    assert "gcnt/temperature:0" in names and len(names) == 3, names
+    assert m1.vars["gcnt/temperature:0"] is m1.temperature
+    layer_vars = [v for layer in m1.layers for v in layer.vars.values()]
+    assert all(m1.vars[v.name] is v for v in layer_vars) and len(layer_vars) == 2
+    m2 = WithTemperature(placeholders(), input_dim=5, name="gcnt")
+    assert m2.vars["gcnt/temperature:0"] is m2.temperature is not m1.temperature
+    assert len(m2.vars) == 3 and not (set(map(id, m2.vars.values())) & set(map(id, m1.vars.values())))
+    plain = models.GCN(placeholders(), input_dim=5)
+    assert len(plain.vars) == 2
+    tf.reset_default_graph()

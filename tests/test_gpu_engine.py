@@ -313,8 +313,9 @@ def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden, 
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    # (the same edge factor on both sides: bench.py's default differs between one GPU and several)
     common = ["--scale", "14", "--steps", "3", "--warmup", "0", "--cpu-rows", "0", "--hidden", str(hidden),
-              "--features", str(features), "--order", order]
+              "--features", str(features), "--order", order, "--edge-factor", "8"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
                          capture_output=True, text=True, timeout=200, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -327,8 +328,38 @@ def test_bench_two_ranks_match_one_rank_on_one_gpu(halo_mode, features, hidden, 
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["config"]["nnz_a_hat"] == j2["config"]["nnz_a_hat"]
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["halo_mode"] == halo_mode
+    assert "avg degree 16" in j1["config"]["workload"] and "avg degree 16" in j2["config"]["workload"]
+    assert j2["one_gpu_denominator"]["command"] == "python bench.py --scale 13 --edge-factor 8"
     assert abs(j1["final_xent"] - j2["final_xent"]) <= 1e-5 * abs(j1["final_xent"])
     assert abs(j1["final_train_acc"] - j2["final_train_acc"]) <= 1e-6
+
+
+def test_bench_defaults_per_gpu_count():
+    """Without --edge-factor, one GPU runs average degree 16 (the single-GPU headline
+    configuration) and several GPUs run average degree 32 (the row-partitioned
+    configuration: RMAT 2^27 at 8 GPUs); the several-GPU line names the single-GPU
+    run its speed-up refers to."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    common = ["--scale", "12", "--steps", "1", "--warmup", "0", "--cpu-rows", "0", "--hidden", "64", "--features", "32",
+              "--f32-side-steps", "0", "--dense-side-steps", "0"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common,
+                         capture_output=True, text=True, timeout=200, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo"] + common,
+                         capture_output=True, text=True, timeout=200, cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert "avg degree 16" in j1["config"]["workload"] and "one_gpu_denominator" not in j1
+    assert "avg degree 32" in j2["config"]["workload"] and j2["config"]["nnz_a_hat"] > 1.5 * j1["config"]["nnz_a_hat"]
+    assert j2["one_gpu_denominator"]["command"] == "python bench.py --scale 11 --edge-factor 16"
+    assert np.isfinite(j2["final_xent"])
 
 
 def _comm_worker(out_path):
@@ -366,6 +397,16 @@ def _comm_worker(out_path):
     got = torch.zeros_like(words)
     comm.exchange_rows(got.view(torch.float32), words.view(torch.float32), [777], [777]).wait()
     res["words_equal"] = bool(torch.equal(got, words))
+    # (2b) the set-up lists of the halo plan travel the same way: 64-bit row ranges and
+    # counts and 32-bit row ids, viewed as 32-bit words by the engine
+    from gcn_amd.engine import FullBatchGCN
+    ranges = torch.tensor([[123456789012, 77]], dtype=torch.int64, device=dev)
+    got_r = torch.zeros_like(ranges)
+    comm.exchange_rows(FullBatchGCN._as_words(got_r), FullBatchGCN._as_words(ranges), [1], [1]).wait()
+    ids = torch.arange(5, 905, dtype=torch.int32, device=dev)
+    got_i = torch.zeros_like(ids)
+    comm.exchange_rows(FullBatchGCN._as_words(got_i), FullBatchGCN._as_words(ids), [900], [900]).wait()
+    res["setup_lists_equal"] = bool(torch.equal(got_r, ranges) and torch.equal(got_i, ids))
     # (3) nothing to trade is a no-op, and a wrong plan is a status, not a hang
     comm.exchange_rows(torch.empty((0, 4), device=dev), torch.empty((0, 4), device=dev), [0], [0]).wait()
     try:
@@ -411,5 +452,6 @@ def test_cabi_rccl_exchange_single_rank(tmp_path):
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150, cwd=root)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     res = json.load(open(out))
-    assert res == {"gathered_equal": True, "words_equal": True, "bad_counts": "ValueError", "bad_plan": -1,
+    assert res == {"gathered_equal": True, "words_equal": True, "setup_lists_equal": True,
+                   "bad_counts": "ValueError", "bad_plan": -1,
                    "allreduce_equal": True, "self_check": [True, ""]}, res

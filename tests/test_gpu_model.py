@@ -281,7 +281,9 @@ def test_hip_graph_replay_matches_eager(model, dataset):
         F = _setup(model, dataset, 25)
         F.early_stopping = 1000
         F.hip_graph = flag
-        res = train.run(data=data, verbose=False)
+        # (ARPACK's start vector is unseeded: without a pinned eigenvalue the two runs
+        # would train on Chebyshev supports that differ in their last bits)
+        res = train.run(data=data, verbose=False, largest_eigval=2.0 if model == "gcn_cheby" else None)
         sess = res["session"]
         assert sess.hip_graph == flag
         assert sess.graph_replays == (2 * 24 if flag else 0)

@@ -105,3 +105,56 @@ def test_static_scratch_spmm_matches_workspace_spmm():
                                           1.0, 0.0, None, None, 1.0, 0, _stream())
     assert rc == _lib.ERR_WORKSPACE
     assert b"built-in scratch array" in lib.gcnx_last_error()
+
+
+def test_static_scratch_spmm_allocates_nothing_and_records_into_a_graph():
+    """The claim itself: across a call of gcnx_spmm_csr_static_f32 neither torch's
+    allocator nor the device's free memory (hipMemGetInfo) moves, and the call can
+    be recorded in a HIP graph (stream capture forbids allocation) and replayed:
+    the replay writes the bits of the eager call."""
+    import torch
+    from gcn_amd import _lib, rmat
+    from gcn_amd.sparse import _ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    a = rmat.rmat_ahat(15, 8, 123, dev)            # builds its chunk table: the array's address is resolved here
+    assert a.nnz > (1 << 18)
+    width = 32
+    assert 0 < lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width) <= _lib.SPMM_STATIC_SCRATCH_BYTES
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    b = torch.rand((a.n_cols, width), device=dev, generator=g) - 0.5
+    out = torch.empty((a.n_rows, width), dtype=torch.float32, device=dev)
+    ref = torch.empty_like(out)
+
+    def call(dst, stream):
+        with torch.cuda.device(dev):
+            rc = lib.gcnx_spmm_csr_static_f32(a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0), _ptr(dst),
+                                              dst.stride(0), width, 1.0, 0.0, None, None, 1.0, 1,
+                                              C.c_void_p(stream.cuda_stream))
+        assert rc == 0, lib.gcnx_last_error()
+
+    call(ref, torch.cuda.current_stream())          # (a first call, so that nothing below is anybody's first)
+    torch.cuda.synchronize()
+    alloc0, reserved0 = torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    free0, _ = torch.cuda.mem_get_info(dev)
+    call(out, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert torch.cuda.memory_allocated(dev) == alloc0 and torch.cuda.memory_reserved(dev) == reserved0
+    assert free1 == free0, (free0, free1)
+    assert torch.equal(out, ref)
+    # recorded and replayed
+    out.fill_(float("nan"))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(out, torch.cuda.current_stream())      # the capturing stream
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all())             # recording launches nothing
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    b.mul_(2.0)                                     # the graph reads the operand where it lies
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref * 2.0)
