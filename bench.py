@@ -546,7 +546,7 @@ def main():
             # WRITE_SIZE; separate runs of tools/spmm_bench.py on the same matrix and
             # width), folded into bytes in profiles/spmm_hbm_traffic.json.  It is NOT
             # measured in this run: the counters need the profiler attached.
-            traffic, traffic_source = None, None
+            traffic, traffic_source, l2_hit, physical_note = None, None, None, None
             try:
                 with open(os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")) as fh:
                     rec = json.load(fh)
@@ -554,6 +554,8 @@ def main():
                         rec.get("edge_factor", 8) == args.edge_factor:
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_source = "static: profiles/spmm_hbm_traffic.json <- " + str(rec.get("source"))
+                    l2_hit = rec.get("l2_hit_rate")
+                    physical_note = rec.get("hbm_bytes_physical_note")
             except (OSError, ValueError):
                 pass
             result["roofline"] = {
@@ -562,6 +564,9 @@ def main():
                           % args.hidden,
                 "achieved": bytes_ / avg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_is": "bytes that leave the L2s towards memory per launch (FETCH_SIZE x 2 + WRITE_SIZE): "
+                              "Infinity-Cache hits are inside this figure",
+                "hbm_bytes_physical": None, "hbm_bytes_physical_note": physical_note, "l2_hit_rate": l2_hit,
                 "timed_window": "HIP events on the launch stream around the main pass and the fix-up pass",
                 "algorithmic_bytes_per_launch": bytes_, "avg_launch_ms": avg * 1e3,
                 "launches_timed": len(ms), "kernel_nnzF_per_s": a.nnz * args.hidden / avg,

@@ -19,6 +19,7 @@
 // the result does not depend on scheduling.
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 #include "gcnx_common.h"
 #include "gcnx_philox.h"
@@ -484,6 +485,10 @@ __device__ __forceinline__ void split8(const float (&x)[8], i4s &oh, i4s &om, i4
 
 template <int NT, bool FULL, bool SPLIT>
 __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const SpmmArgs a) {
+  // the ragged form (a last slab of fewer tiles) exists for 4-tile slabs only: with 8
+  // tiles its per-tile bounds and the per-half row state do not fit the scalar
+  // registers together
+  static_assert(FULL || NT <= 4, "ragged slabs are served by the 4-tile form");
   constexpr int HW = 32;     // lanes per half
   const int lane = threadIdx.x & (kWave - 1);
   const int li = lane & 31, h = lane >> 5;
@@ -536,46 +541,77 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
   // the same in every lane; held as a scalar so that the round loops are scalar loops
   const int nk_max = __builtin_amdgcn_readfirstlane(nk > nk_other ? nk : nk_other);
 
-  int64_t r = live ? (int64_t)a.chunk_row[ch * a.chunk_mul] : a.n_rows;
-  int64_t rbase = r;
-  // half-held window: lane li holds the end (relative to n0) of row rbase + li
-  auto load_row_ends = [&](int64_t rb) -> int {
+  // Row bookkeeping.  The two halves walk different chunks, but within a half every
+  // lane is at the same row: the state of each half (open row, its start and end,
+  // the output pointer) is held in scalar registers, one set per half, and a row
+  // end is a scalar compare.  Only the stores and the clearing of the accumulators
+  // run under the half's lane mask.
+  const int r_v = live ? a.chunk_row[ch * a.chunk_mul] : (int)a.n_rows;
+  // half-held windows: lane li holds the end (relative to n0) of row rb + li; the
+  // window after the current one is fetched a window ahead
+  // (the window ahead is kept as loaded and only turned into row ends when it
+  // becomes current, so that nothing waits for the load where it is issued)
+  auto load_row_ptrs = [&](int64_t rb) -> int64_t {
     const int64_t rr = rb + 1 + li;
-    if (rr > a.n_rows) return kRowEndBeyond;
-    const int64_t e = a.row_ptr[rr] - n0;
+    return rr > a.n_rows ? INT64_MAX : a.row_ptr[rr];
+  };
+  auto row_ends = [&](int64_t ptrs) -> int {       // beyond the chunk (or the matrix): chunk + 1
+    const int64_t e = ptrs - n0;
     return e > (int64_t)chunk ? chunk + 1 : (int)e;
   };
-  int re_v = load_row_ends(rbase);
-  int re = __shfl(re_v, h * HW, kWave);
-  int rs = -1;
-  if (live && r < a.n_rows) {
-    const int64_t s0 = a.row_ptr[r] - n0;
-    rs = s0 < 0 ? -1 : (int)s0;
+  int re_v = row_ends(load_row_ptrs(r_v));
+  int64_t nx_ptrs = load_row_ptrs((int64_t)r_v + HW);
+  int rs_v = -1;
+  if (live && r_v < a.n_rows) {
+    const int64_t s0 = a.row_ptr[r_v] - n0;
+    rs_v = s0 < 0 ? -1 : (int)s0;
   }
+  const int64_t wave_s = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wid);
+  int r_s[2], rbase_s[2], re_s[2], rs_s[2];
+  float *crow_s[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    r_s[hh] = rbase_s[hh] = __builtin_amdgcn_readlane(r_v, HW * hh);
+    re_s[hh] = __builtin_amdgcn_readlane(re_v, HW * hh);
+    rs_s[hh] = __builtin_amdgcn_readlane(rs_v, HW * hh);
+    crow_s[hh] = a.C + (int64_t)r_s[hh] * a.ldc + cbase;             // lane li: + li
+  }
+  // the half's partial-sum slots (first row continued from the chunk before, last
+  // row continued in the chunk after); needed twice per chunk, formed on demand
+  auto pslot_of = [&](int hh) -> float * {
+    const int64_t ch_s = 2 * wave_s + hh;
+    return a.partial + (size_t)(ch_s < a.n_chunks ? ch_s : 0) * 2 * a.pwidth + cbase;
+  };
   float acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = 0.0f;
-  float *const pslot = a.partial + (size_t)(live ? ch : 0) * 2 * a.pwidth + cbase + li;
 
-  float *crow = a.C + r * a.ldc + cbase + li;   // this lane's first column of row r
-  auto close_row = [&]() {
-    float *dst = rs < 0 ? pslot : crow;
+  auto close_half = [&](auto HH) {
+    constexpr int hh = decltype(HH)::value;
+    float *const dst = rs_s[hh] < 0 ? pslot_of(hh) : crow_s[hh];
+    if (h == hh) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t < nt) dst[32 * t] = acc[t];
-      acc[t] = 0.0f;
+      for (int t = 0; t < NT; ++t) {
+        if (t < nt) dst[li + 32 * t] = acc[t];
+        acc[t] = 0.0f;
+      }
     }
-    rs = re;
-    ++r;
-    crow += a.ldc;
-    int idx = (int)(r - rbase);
+    rs_s[hh] = re_s[hh];
+    ++r_s[hh];
+    crow_s[hh] += a.ldc;
+    int idx = r_s[hh] - rbase_s[hh];
     if (idx == HW) {
-      rbase = r;
-      re_v = load_row_ends(rbase);
+      rbase_s[hh] = r_s[hh];
+      if (h == hh) {
+        re_v = row_ends(nx_ptrs);
+        nx_ptrs = load_row_ptrs((int64_t)rbase_s[hh] + HW);
+      }
       idx = 0;
     }
-    re = __shfl(re_v, h * HW + idx, kWave);
+    re_s[hh] = __builtin_amdgcn_readlane(re_v, HW * hh + idx);
   };
+  const std::integral_constant<int, 0> kHalf0;
+  const std::integral_constant<int, 1> kHalf1;
 
   // MFMA row i = li of the A operand is nonzero an of half ah
   const int ah = (li >> 2) & 1, an = (li & 3) + 4 * (li >> 3);
@@ -619,10 +655,12 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
         const int k = k0 + n;
-        // row bookkeeping is per half (divergent); the arithmetic below is not.
-        // (Past the end of a chunk k can only meet a row end that lies exactly on
-        // the chunk end, which the loop after the rounds would close anyway.)
-        while (k == re) close_row();
+        // row ends of either half (scalar compares); the arithmetic below runs on
+        // both halves at once.  (Past the end of a chunk k can only meet a row end
+        // that lies exactly on the chunk end, which the loop after the rounds would
+        // close anyway.)
+        while (k == re_s[0]) close_half(kHalf0);
+        while (k == re_s[1]) close_half(kHalf1);
         const int src = 16 * sb + n;
         // exact form: the half's own matrix value (LDS crossbar, no vector-ALU slot);
         // split form: the value already multiplies the D row, the update is an addition
@@ -829,15 +867,22 @@ __global__ __launch_bounds__(kBlock, 2) void spmm_factored_mfma_kernel(const Spm
       }
     }
   }
-  if (live) {
-    while (re <= nk) close_row();
-    if (r < a.n_rows && rs < nk) {
-      float *dst = pslot + (rs < 0 ? 0 : a.pwidth);
+  auto finish_half = [&](auto HH) {
+    constexpr int hh = decltype(HH)::value;
+    if (2 * wave_s + hh >= a.n_chunks) return;
+    const int nk_h = __builtin_amdgcn_readlane(nk, HW * hh);
+    while (re_s[hh] <= nk_h) close_half(HH);
+    if (r_s[hh] < a.n_rows && rs_s[hh] < nk_h) {
+      float *const dst = pslot_of(hh) + (rs_s[hh] < 0 ? 0 : a.pwidth);
+      if (h == hh) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < nt) dst[32 * t] = acc[t];
+        for (int t = 0; t < NT; ++t)
+          if (t < nt) dst[li + 32 * t] = acc[t];
+      }
     }
-  }
+  };
+  finish_half(kHalf0);
+  finish_half(kHalf1);
 }
 
 // Narrow dense operands (at most 32 lanes wide): the wavefront is cut into
@@ -1561,7 +1606,6 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
     else hipLaunchKernelGGL((spmm_factored_mfma_kernel<NTV, FULLV, false>), dim3(gxp, (unsigned)(GY)), dim3(kBlock), 0, st, k);      \
   } while (0)
     if (width % 256 == 0) GCNX_FACT(8, true, width / 256);
-    else if (width > 512) GCNX_FACT(8, false, ceil_div(width, 256));
     else if (width % 128 == 0) GCNX_FACT(4, true, width / 128);
     else GCNX_FACT(4, false, ceil_div(width, 128));
 #undef GCNX_FACT
@@ -1576,5 +1620,6 @@ extern "C" int gcnx_spmm_csr_factored_f32(const gcnx_csr *a, const int32_t *chun
   if (g_prof_stop) GCNX_CHECK_HIP(hipEventRecord(g_prof_stop, st));
   return GCNX_OK;
 }
+
 
 
