@@ -151,6 +151,36 @@ def cpu_epoch_baseline(scale, args, dev):
     }
 
 
+def planetoid_epochs(epochs):
+    """Side measurement for the small-graph configurations: the drop-in path
+    (gcn.utils -> gcn.models -> sess.run, each sess.run replayed from a HIP graph)
+    trained for `epochs` epochs on Cora (gcn), Pubmed (gcn; real graph, labels and
+    splits, shape-matched SYNTHETIC features: the feature blob is not distributed
+    with the reference tree, so its accuracy means nothing) and Citeseer
+    (gcn_cheby, K = 3), with the reference's flags (dropout 0.5, hidden 16, early
+    stopping after 10 epochs without improvement).  Epoch = one training step + one
+    validation forward, as the reference's loop runs them (gcn/train_normal.py:79-100)."""
+    from gcn_amd import tfcompat as tf, train, utils
+    train.define_flags()
+    F = tf.app.flags.FLAGS
+    F._parse([])
+    F.hip_graph = True
+    out = []
+    for ds, model in (("cora", "gcn"), ("pubmed", "gcn"), ("citeseer", "gcn_cheby")):
+        F.dataset, F.model, F.epochs = ds, model, epochs
+        data = utils.load_pubmed_synthetic_features() if ds == "pubmed" else utils.load_data(ds)
+        t0 = time.perf_counter()
+        res = train.run(data=data, verbose=False)
+        wall = time.perf_counter() - t0
+        ms = sorted(r[4] * 1e3 for r in res["trace"][5:]) or [float("nan")]
+        out.append({"dataset": ds, "model": model, "features": "synthetic" if ds == "pubmed" else "real",
+                    "epochs": res["epochs_run"], "epoch_ms_median": ms[len(ms) // 2], "epoch_ms_min": ms[0],
+                    "test_acc": res["test_acc"] if ds != "pubmed" else None, "hip_graph": True,
+                    "wall_s_with_setup": wall})
+        tf.reset_default_graph()
+    return out
+
+
 def one_gpu_denominator(args, shard_scale):
     """The single-GPU run a multi-GPU line's speed-up refers to: the same shard shape
     (2^shard_scale rows, same degree, widths and arithmetic) alone on one GPU,
@@ -220,6 +250,9 @@ def main():
     ap.add_argument("--cpu-epoch-scale", type=int, default=18,
                     help="one GPU: log2 of the node count of the small RMAT instance on which the oracle's full "
                          "training epoch is timed on the host next to the GPU's (cpu_baseline.epoch; 0 = skip)")
+    ap.add_argument("--planetoid-epochs", type=int, default=200,
+                    help="one GPU: also train the drop-in path on Cora / Pubmed (gcn) and Citeseer (gcn_cheby) for "
+                         "this many epochs and report their epoch times (planetoid; 0 = skip)")
     ap.add_argument("--dense-side-steps", type=int, default=3,
                     help="after the timed steps, time this many steps with the dense backward products as a side "
                          "measurement (ms_per_step_dense_gradients; 0 = skip)")
@@ -609,6 +642,11 @@ def main():
                     result["cpu_baseline"]["epoch"] = cpu_epoch_baseline(args.cpu_epoch_scale, args, dev)
                 except Exception as exc:
                     result["cpu_baseline"]["epoch"] = {"cpu_ms": None, "failed": repr(exc)}
+        if args.planetoid_epochs > 0 and world == 1 and scale >= 20:
+            try:
+                result["planetoid"] = planetoid_epochs(args.planetoid_epochs)
+            except Exception as exc:    # a side measurement: never lose the line
+                result["planetoid"] = {"failed": repr(exc)}
         if world > 1:
             # what the node-level speed-up of this configuration is measured against: the
             # same per-GPU shard shape (2^24 rows, this degree) run alone on one GPU
