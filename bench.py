@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--dense-side-steps", type=int, default=3,
                     help="after the timed steps, time this many steps with the dense backward products as a side "
                          "measurement (ms_per_step_dense_gradients; 0 = skip)")
+    ap.add_argument("--blocking-class-exchange", action="store_true",
+                    help="several GPUs: form the class-width forward product in one piece behind a blocking halo "
+                         "exchange (row sums in column order as on one GPU: results bitwise independent of the GPU "
+                         "count); default: local columns during the exchange, halo columns after it")
     ap.add_argument("--dense-loss-gradient", action="store_true",
                     help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
                          "labelled columns only (the other rows of dZ are exactly zero; same result)")
@@ -387,7 +391,8 @@ def main():
         return engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2,
                           row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
                           slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
-                          sparse_loss_gradient=not args.dense_loss_gradient)
+                          sparse_loss_gradient=not args.dense_loss_gradient,
+                          overlap_class_exchange=not args.blocking_class_exchange)
 
     model = make_engine()
     nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
@@ -546,6 +551,8 @@ def main():
                 "halo_mode": ("none" if world == 1 else "recompute" if model.recompute else "exchange"),
                 "exchange": ("none" if world == 1 else "gcnx_halo_allgather_f32 (RCCL inside libgcnhip.so)"
                              if comm is not None else "torch.distributed " + args.backend),
+                "class_width_exchange": ("none" if world == 1 else "overlapped (local columns first)"
+                                         if model.fwd_local is not None else "blocking"),
                 "order": args.order, "dense_arith": args.dense_arith,
                 "nnz_loss_gradient_product": nnz_dz_global, "nnz_backward_product": nnz_bwd_global,
                 "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),

@@ -59,7 +59,7 @@ class FullBatchGCN(object):
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
                  kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None,
-                 sparse_loss_gradient=True):
+                 sparse_loss_gradient=True, overlap_class_exchange=True):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -81,7 +81,15 @@ class FullBatchGCN(object):
         neighbour (the other rows of dP2, hence of d(A P1), are exactly zero) --
         sub-matrices built once, the label mask being fixed; every row of every
         gradient is still written and no sum changes (False: the full matrix,
-        zeros multiplied as the reference does)."""
+        zeros multiplied as the reference does).
+        ``overlap_class_exchange`` (several ranks): the class-width forward product
+        A_hat [P2; halo rows of P2] is formed in two parts -- the nonzeros of the
+        local columns while the halo rows travel, the nonzeros of the halo columns
+        added once they are in -- so that no exchange of the step blocks the
+        compute stream; a row's sum is then grouped (local terms, then halo terms)
+        instead of running in column order, so one rank and several agree to fp32
+        rounding, not to the bit (False: one product after the exchange, bitwise
+        independent of the rank count)."""
         self.k = kernels if kernels is not None else _hip_ops
         self.comm = comm
         self.a = a_local
@@ -157,10 +165,12 @@ class FullBatchGCN(object):
             else:
                 self.recompute = self._setup_recompute(halo_mode)
             self._setup_label_exchange()
+            self._setup_class_overlap(overlap_class_exchange)
         else:
             self.slab = None
             self.recompute = False
             self.dz_plan = None
+            self.fwd_local = self.fwd_halo = None
         self._setup_loss_gradient_matrix(sparse_loss_gradient)
         self._setup_backward_matrix()
         # the hidden-width forward product gathers 4 h bytes per nonzero from an operand
@@ -227,6 +237,34 @@ class FullBatchGCN(object):
         self.dp2_send, self.dp2_halo = e(ns, self.c), e(nh, self.c)
         self._bits_work = None
         return True
+
+    def _setup_class_overlap(self, enabled):
+        """``self.fwd_local`` / ``self.fwd_halo``: the forward block cut by column into
+        the nonzeros that meet local rows of the operand and those that meet halo
+        rows (sub-matrices of the same shape, built once), or None."""
+        self.fwd_local = self.fwd_halo = None
+        filt = getattr(self.k, "csr_filter_columns", None)
+        plan = self.plan
+        if not enabled or filt is None or plan.n_halo == 0 or self.c > self.slab:
+            return
+        is_halo = torch.zeros(self.n_loc + plan.n_halo, dtype=torch.uint8, device=self.dev)
+        is_halo[self.n_loc:] = 1
+        self.fwd_halo = filt(plan.csr, is_halo)
+        self.fwd_local = filt(plan.csr, 1 - is_halo)
+
+    def _aggregate_class_overlapped(self, src, dst):
+        """dst = A_hat [src; halo rows of src] with the exchange of the halo rows
+        hidden behind the local part of the product."""
+        plan = self.plan
+        w = src.shape[1]
+        sb = self.sendbuf[0][:plan.n_send * w].view(plan.n_send, w)
+        hb = self.halobuf[0][:plan.n_halo * w].view(plan.n_halo, w)
+        work = self._exchange_start(plan, src, 0, w, sb, hb)
+        # the local columns' nonzeros never read the halo buffer (it is being written)
+        self.k.spmm(self.fwd_local, src, out=dst, b2=hb)
+        if work is not None:
+            work.wait()
+        self.k.spmm(self.fwd_halo, src, out=dst, b2=hb, beta=1.0)
 
     def _flagged_subplan(self, plan, local_flag):
         """The part of ``plan`` that concerns the flagged rows (``local_flag``: one
@@ -553,7 +591,7 @@ class FullBatchGCN(object):
         else:
             k.gemm(self.ax, self.w1, out=self.hd, relu=True, dropout=drop)
         k.gemm(self.hd, self.w2, out=self.p2)
-        self._aggregate("fwd", self.p2, self.z, relu=False)
+        self._aggregate_logits()
         return xin, self.hd, None
 
     def forward(self, train):
@@ -622,8 +660,15 @@ class FullBatchGCN(object):
                             sign_bits=self.hbits if (train and self.world == 1) else None)
         hin = self.hd
         k.gemm(hin, self.w2, out=self.p2)
-        self._aggregate("fwd", self.p2, self.z, relu=False)
+        self._aggregate_logits()
         return xin, hin, xdrop
+
+    def _aggregate_logits(self):
+        """Z = A_hat P2 (class width)."""
+        if self.fwd_local is not None:
+            self._aggregate_class_overlapped(self.p2, self.z)
+        else:
+            self._aggregate("fwd", self.p2, self.z, relu=False)
 
     def loss(self, want_grad):
         out, _ = self.k.masked_softmax_xent(self.z, self.y, self.ymask, want_grad=want_grad,

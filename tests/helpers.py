@@ -115,10 +115,14 @@ class OracleKernels(object):
     def spmm_supports_sign_bits(self, width):
         return width % 32 == 0
 
-    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, sign_bits=None, **kw):
+    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, sign_bits=None, alpha=1.0, beta=0.0, **kw):
         if b2 is not None:
             b = self.torch.cat([b, b2], 0)
         r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
+        if alpha != 1.0:
+            r = r * np.float32(alpha)
+        if beta != 0.0:
+            r = (r + np.float32(beta) * out.numpy()).astype(np.float32)
         if relu:
             r = np.maximum(r, 0)
         if dropout is not None and dropout[0] < 1.0:

@@ -34,7 +34,7 @@ def _problem(scale=7, f=12, hidden=16, classes=5, label_rate=0.3):
 
 
 def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="reference", tag="", dropout=0.5,
-         classes=5, uneven=False, label_rate=0.3, scale=7):
+         classes=5, uneven=False, label_rate=0.3, scale=7, overlap=True):
     from gcn_amd import engine
     if world > 1:
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -54,9 +54,15 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
         CpuCsr(a_hat[rb:re_]), T(x[rb:re_].copy()), T(labels[rb:re_].copy()), T(lmask[rb:re_].copy()),
         int(lmask.sum()), hidden, classes, T(w1), T(w2), row_begin=rb, n_global=n, seed=5,
         group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank, slab_cols=slab,
-        kernels=OracleKernels(), halo_mode=halo_mode, order=order, dropout=dropout)
+        kernels=OracleKernels(), halo_mode=halo_mode, order=order, dropout=dropout, overlap_class_exchange=overlap)
     if world > 1:
         assert eng.recompute == (halo_mode == "recompute" and order == "reference")
+        # the class-width forward product in two parts (local columns during the exchange,
+        # halo columns after it) whenever the class width fits one slab
+        assert (eng.fwd_local is not None) == (overlap and eng.plan.n_halo > 0 and classes <= eng.slab)
+        if eng.fwd_local is not None:
+            assert eng.fwd_local.nnz + eng.fwd_halo.nnz == eng.plan.csr.nnz
+            assert int(eng.fwd_local.col_idx.max(initial=0)) < eng.n_loc <= int(eng.fwd_halo.col_idx.min(initial=1 << 30))
         # the halo rows of the loss gradient that travel are exactly the labelled ones
         need = eng.plan_bwd.need.numpy().astype(np.int64)
         assert eng.dz_plan is not None and eng.dz_plan.n_halo == int(lmask[need].sum())
@@ -279,3 +285,27 @@ def test_single_rank_matches_model_oracle():
         assert abs(got[0] - xent) <= 1e-5 * abs(xent)
         np.testing.assert_allclose(eng.w1.numpy(), orc.w[0][0], rtol=0, atol=2e-6)
         np.testing.assert_allclose(eng.w2.numpy(), orc.w[1][0], rtol=0, atol=2e-6)
+
+
+def test_overlapped_and_blocking_class_exchange_agree(tmp_path):
+    """The forward class-width product with its halo exchange hidden (two partial
+    products) against the one product behind a blocking exchange: same losses and
+    weights to rounding on 2 ranks; the blocking form is the one whose row sums run
+    in column order as on one rank."""
+    out = str(tmp_path)
+    _run(0, 1, 0, None, out, "auto", 64, classes=16)
+    for overlap, tag in ((True, "_ov"), (False, "_bl")):
+        mp.spawn(_run, args=(2, _free_port(), 16, out, "recompute", 64, "reference", tag, 0.5, 16, False, 0.3, 7, overlap),
+                 nprocs=2, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    ov = np.load(os.path.join(out, "w2_r0_ov.npz"))
+    bl = np.load(os.path.join(out, "w2_r0_bl.npz"))
+    for got in (ov, bl):
+        np.testing.assert_allclose(got["outs"], one["outs"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(got["w1"], one["w1"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got["w2"], one["w2"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ov["outs"], bl["outs"], rtol=1e-5, atol=1e-7)
+    z_ov = np.concatenate([np.load(os.path.join(out, "w2_r%d_ov.npz" % r))["z"] for r in range(2)])
+    z_bl = np.concatenate([np.load(os.path.join(out, "w2_r%d_bl.npz" % r))["z"] for r in range(2)])
+    np.testing.assert_allclose(z_ov, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
+    np.testing.assert_allclose(z_bl, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
