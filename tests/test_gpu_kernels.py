@@ -1200,3 +1200,39 @@ def test_interleaved_supports_equal_sum_of_products(env, n_sup, width, f64):
         mag += m64
     assert_close_to_f64(got, ref64, mag, what="merged supports S=%d w=%d" % (n_sup, width))
     assert rel_maxnorm(got, ref32) <= RTOL
+
+
+def test_autograd_backward_runs_in_the_forward_products_arithmetic(env):
+    """The arithmetic mode of the large products is a per-thread setting of the
+    library and torch runs backward on a thread of its own: the tape node carries the
+    forward call's mode.  With fp32 chains selected on the calling thread, both
+    gradients of a product whose shapes the split-operand kernels would serve equal,
+    bit for bit, the fp32-chain products formed directly on the calling thread -- and
+    differ from the split-operand ones (so the check can tell the two apart)."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    a = (torch.rand((1024, 256), device=dev, generator=g) - 0.5).requires_grad_(True)
+    b = (torch.rand((256, 256), device=dev, generator=g) - 0.5).requires_grad_(True)
+    dy = torch.rand((1024, 256), device=dev, generator=g) - 0.5
+    before = ops.dense_arith(1)
+    try:
+        y = ops.gemm_autograd(a, b)
+        da, db = torch.autograd.grad(y, [a, b], dy)
+        want_da = ops.gemm(dy, b.detach(), trans_b=True)
+        want_db = ops.gemm(a.detach(), dy, trans_a=True)
+        assert ops.dense_arith() == 1                 # the calling thread's mode is untouched
+    finally:
+        ops.dense_arith(before)
+    assert torch.equal(da, want_da) and torch.equal(db, want_db)
+    split_da = ops.gemm(dy, b.detach(), trans_b=True)           # default arithmetic: exactly split operands
+    assert not torch.equal(split_da, want_da)
+    assert float((split_da - want_da).abs().max()) <= 1e-5 * float(want_da.abs().max())
+    # and the other way round: a forward product in the default arithmetic keeps it in backward
+    y0 = ops.gemm_autograd(a, b)
+    before = ops.dense_arith(1)
+    try:
+        da0, = torch.autograd.grad(y0, [a], dy)                  # backward asked for while fp32 chains are selected
+    finally:
+        ops.dense_arith(before)
+    assert torch.equal(da0, split_da)
