@@ -575,12 +575,9 @@ def main():
             "ms_per_step_dense_gradients": dense_ms,
             "ms_per_step_f32_chains": f32_ms,
             "ms_per_step_f32_chains_dense_gradients": f32_dense_ms,
-            "side_measurements": "ms_per_step is the timed region (dense_arith as in config; backward products over "
-                                 "the nonzeros and rows the masked loss can reach).  ms_per_step_dense_gradients: the "
-                                 "same engine with every backward product over every nonzero and row, as the "
-                                 "reference multiplies.  ms_per_step_f32_chains(_dense_gradients): a second engine with "
-                                 "every dense product on exact fp32 MFMA chains (--dense-arith f32).  All after the "
-                                 "timed region, a few steps each, not part of value.",
+            "side_measurements": "after the timed region, a few steps each, not part of value: _dense_gradients = every "
+                                 "backward product over every nonzero and row, as the reference multiplies; _f32_chains "
+                                 "= a second engine with every dense product on exact fp32 MFMA chains",
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,
         }
@@ -601,7 +598,10 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_source = "static: profiles/spmm_hbm_traffic.json <- " + str(rec.get("source"))
                     l2_hit = rec.get("l2_hit_rate")
-                    physical_note = rec.get("hbm_bytes_physical_note")
+                    if rec.get("hbm_bytes_physical_note"):
+                        physical_note = ("no counter on this box separates HBM service from Infinity-Cache service "
+                                         "(TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ for this kernel); details in "
+                                         "profiles/spmm_hbm_traffic.json")
             except (OSError, ValueError):
                 pass
             result["roofline"] = {
@@ -610,8 +610,7 @@ def main():
                           % args.hidden,
                 "achieved": bytes_ / avg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
-                "traffic_is": "bytes that leave the L2s towards memory per launch (FETCH_SIZE x 2 + WRITE_SIZE): "
-                              "Infinity-Cache hits are inside this figure",
+                "traffic_is": "bytes leaving the L2s per launch (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included",
                 "hbm_bytes_physical": None, "hbm_bytes_physical_note": physical_note, "l2_hit_rate": l2_hit,
                 "timed_window": "HIP events on the launch stream around the main pass and the fix-up pass",
                 "algorithmic_bytes_per_launch": bytes_, "avg_launch_ms": avg * 1e3,
