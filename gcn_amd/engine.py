@@ -59,7 +59,7 @@ class FullBatchGCN(object):
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
                  kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None,
-                 sparse_loss_gradient=True, overlap_class_exchange=True):
+                 sparse_loss_gradient=True, overlap_class_exchange=True, pack_gate_operands=True):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -194,6 +194,23 @@ class FullBatchGCN(object):
         sup_f = getattr(self.k, "spmm_supports_factored", None)
         self.factored_bwd = bool(not agg_first and self.hbits is not None and self.keep > 0.0 and sup_f is not None and
                                  sup_f(self.h, self.c))
+        words = self.h // 32
+        if self.factored_bwd and pack_gate_operands and self.c % 4 == 0 and 4 * (self.c + words) <= 128:
+            # The factored product gathers, per nonzero, the node's row of dP2 and its sign
+            # words: kept side by side in one 128-byte record per node, the two gathers of
+            # a nonzero fall into one memory line instead of two (both arrays become
+            # strided views of the record array; their producers write through the views)
+            self._gate_records = torch.zeros((nl, 32), dtype=torch.float32, device=self.dev)
+            self.dp2 = self._gate_records[:, :self.c]
+            self.hbits = self._gate_records.view(torch.int32)[:, self.c:self.c + words]
+            if self.world > 1 and self.recompute and self.hit_plan is not None:
+                # the halo rows likewise (they are put in place row by row with
+                # gcnx_scatter_rows_f32, which takes any row pitch; the rows that never
+                # arrive stay zero)
+                nh = max(self.plan.n_halo, 1)
+                self._gate_records_halo = torch.zeros((nh, 32), dtype=torch.float32, device=self.dev)
+                self.dp2_halo = self._gate_records_halo[:, :self.c]
+                self.hbits_halo = self._gate_records_halo.view(torch.int32)[:, self.c:self.c + words]
 
     def _hint_forward_matrix(self):
         width = self.f if self.order == "aggregate_first" else self.h
@@ -421,6 +438,12 @@ class FullBatchGCN(object):
         process; not reversible)."""
         self.at_dz = self.at_dz_c = self.dz_rows = self.p1_c = self.ax_c = None
         self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
+        if self.hit_plan is not None and getattr(self, "_gate_records_halo", None) is not None:
+            # the full exchanges deliver straight into the halo operands: contiguous buffers again
+            nh = max(self.plan.n_halo, 1)
+            self.dp2_halo = torch.empty((nh, self.c), dtype=torch.float32, device=self.dev)
+            self.hbits_halo = torch.empty((nh, self.h // 32), dtype=torch.int32, device=self.dev)
+            self._gate_records_halo = None
         self.hit_plan = None                        # every halo row of dP2 and of the sign words travels again
         if self.hb is None and self.order != "aggregate_first":
             self.hb = torch.empty((self.n_loc, self.h), dtype=torch.float32, device=self.dev)

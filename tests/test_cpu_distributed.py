@@ -72,6 +72,11 @@ def _run(rank, world, port, slab, out_dir, halo_mode="auto", hidden=16, order="r
     # with the factored operand (dP2 rows + sign words, local and halo)
     assert eng.factored_bwd == (classes == 16 and hidden % 64 == 0 and order == "reference" and
                                 (world == 1 or eng.recompute))
+    if eng.factored_bwd:
+        # local (and, with the sub-plan exchange, halo) operands of the factored product in 128-byte records
+        assert eng.dp2.stride(0) == 32 == eng.hbits.stride(0)
+        if world > 1 and eng.hit_plan is not None:
+            assert eng.dp2_halo.stride(0) == 32 == eng.hbits_halo.stride(0)
     outs = [eng.train_step().numpy().copy() for _ in range(3)]
     ev = eng.evaluate().numpy().copy()
     np.savez(os.path.join(out_dir, "w%d_r%d%s.npz" % (world, rank, tag)), outs=np.stack(outs), ev=ev,

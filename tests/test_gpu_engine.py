@@ -90,6 +90,10 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     order = order.split("-")[0]
     eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
                                      T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz)
+    if hidden == 256 and classes == 16 and order == "reference":
+        # the operands of the factored backward product lie side by side, one 128-byte record per node
+        assert eng.factored_bwd and eng.dp2.stride(0) == 32 == eng.hbits.stride(0)
+        assert eng.hbits.data_ptr() - eng.dp2.data_ptr() == 64
     if sparse_dz:
         # the product A_hat^T dZ runs over the nonzeros of the labelled columns only
         want_nnz = int(lmask[a.col_idx.cpu().numpy()].sum())
