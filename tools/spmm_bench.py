@@ -21,6 +21,7 @@ def main():
                     "and as the one-kernel factored SpMM (inner 16)")
     ap.add_argument("--hint", action="store_true", help="attach the cache hint of the wide kernel "
                     "(Csr.set_gather_hint at the first width's row size)")
+    ap.add_argument("--hint-budget-mib", type=float, default=176.0, help="bytes of operand rows the hint keeps cacheable")
     ap.add_argument("--relabel", choices=["none", "degree"], default="none",
                     help="degree: renumber the vertices by descending degree first (hub rows of the operand "
                     "become neighbours in memory)")
@@ -42,7 +43,7 @@ def main():
     print("graph: n=%d nnz=%d max_deg=%d build %.2fs" % (
         a.n_rows, a.nnz, int((a.row_ptr[1:] - a.row_ptr[:-1]).max()), time.time() - t0), flush=True)
     if args.hint:
-        print("gather hint: rows of columns with degree >= %d stay cacheable" % a.set_gather_hint(args.width[0] * 4),
+        print("gather hint: rows of columns with degree >= %d stay cacheable" % a.set_gather_hint(args.width[0] * 4, budget_bytes=int(args.hint_budget_mib * 2 ** 20)),
               flush=True)
     for w in args.width:
         b = torch.rand((a.n_cols, w), device=dev) * 2 - 1
