@@ -260,6 +260,10 @@ def main():
                     help="several GPUs: form the class-width forward product in one piece behind a blocking halo "
                          "exchange (row sums in column order as on one GPU: results bitwise independent of the GPU "
                          "count); default: local columns during the exchange, halo columns after it")
+    ap.add_argument("--every-row", action="store_true",
+                    help="one GPU: form every row of every activation in the training step, as the reference does; "
+                         "default: only the rows the masked loss depends on (the labelled rows of Z, the rows of H' "
+                         "they read, the rows of P1 those read; same loss, accuracy and weight update)")
     ap.add_argument("--dense-loss-gradient", action="store_true",
                     help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
                          "labelled columns only (the other rows of dZ are exactly zero; same result)")
@@ -392,7 +396,8 @@ def main():
                           row_begin=rb, n_global=n, seed=seed, group=group, world_size=world, rank=rank,
                           slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
                           sparse_loss_gradient=not args.dense_loss_gradient,
-                          overlap_class_exchange=not args.blocking_class_exchange)
+                          overlap_class_exchange=not args.blocking_class_exchange,
+                          labelled_field_only=not args.every_row)
 
     model = make_engine()
     nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
@@ -432,7 +437,7 @@ def main():
                 ops.profile_spmm_events(s, e)
                 out = real_spmm(aa, b, **kw)
                 ops.profile_spmm_events(None, None)
-                ev_used.append((s, e))
+                ev_used.append((s, e, int(aa.nnz), int(aa.n_rows)))
                 return out
             return real_spmm(aa, b, **kw)
 
@@ -442,7 +447,7 @@ def main():
             # (the second one sums over the rows of dP1 that can be nonzero: x then holds those rows)
             ta = bool(kw.get("trans_a"))
             big = x.shape[1] == args.features and y.shape[-1] == args.hidden and \
-                ((not ta and x.shape[0] == n_loc and y.shape[0] == args.features) or
+                ((not ta and x.shape[0] >= n_loc // 8 and y.shape[0] == args.features) or
                  (ta and y.shape[0] == x.shape[0] and x.shape[0] >= n_loc // 8))
             if Timed.armed and big and args.order == "reference" and len(gemm_ev) < n_ev:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -486,7 +491,22 @@ def main():
     # Side measurement, outside the timed region and not part of `value`: the same
     # engine with every backward product over every nonzero and row (what
     # --dense-loss-gradient times as the main number), so that both forms come from one run.
-    dense_ms = None
+    dense_ms = every_row_ms = None
+    field = model.field
+    field_info = None
+    if field is not None:
+        field_info = {"labelled_rows": field.n_l, "rows_of_H": field.n1, "rows_of_P1": field.n2,
+                      "nnz_hidden_width": field.nnz_h, "nnz_class_width": field.nnz_z}
+        if args.dense_side_steps > 0:
+            # the same engine forming every row of every activation (backward shortcuts kept)
+            model.field = None
+            model.train_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.dense_side_steps):
+                model.train_step()
+            barrier()
+            every_row_ms = (time.perf_counter() - t1) / args.dense_side_steps * 1e3
     if not args.dense_loss_gradient and model.at_dz is not None and args.dense_side_steps > 0:
         model.use_dense_gradients()
         model.train_step()
@@ -539,7 +559,9 @@ def main():
 
     if rank == 0:
         # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
+        model.field = field          # (the work of the timed steps)
         units = model.spmm_units_per_step(nnz_global, nnz_dz_global, nnz_bwd_global)
+        model.field = None
         result = {
             "metric": "GCN SpMM nnz*F/s (full-batch epoch: fwd + bwd + Adam)",
             "value": units * args.steps / dt,
@@ -562,7 +584,16 @@ def main():
                 "order": args.order, "dense_arith": args.dense_arith,
                 "nnz_loss_gradient_product": nnz_dz_global, "nnz_backward_product": nnz_bwd_global,
                 "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),
-                "spmm_per_step": (("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
+                "rows_formed": ("every row of every activation" if field_info is None else
+                                "only what the masked loss reads: Z at the labelled rows, H' at the rows those read, "
+                                "P1 at the rows those read (same loss, accuracy and weight update; --every-row forms "
+                                "all rows)"),
+                "field": field_info,
+                "spmm_per_step": ("2 x width %d over the %d nonzeros of A_hat[rows of H', rows of P1] + 2 x width %d "
+                                  "over the %d nonzeros of A_hat[labelled rows, rows of H'], counted as such in value"
+                                  % (args.hidden, field_info["nnz_hidden_width"], args.classes,
+                                     field_info["nnz_class_width"])) if field_info is not None else
+                                 (("2 x width %d + 2 x width %d" % (args.hidden, args.classes)
                                    if args.order == "reference" else
                                    "1 x width %d + 2 x width %d" % (args.features, args.classes)) +
                                   ("" if nnz_dz_global == nnz_global else
@@ -572,19 +603,23 @@ def main():
                                    % (nnz_dz_global, nnz_bwd_global))),
             },
             "epoch_ms": dt / args.steps * 1e3,
+            "ms_per_step_every_row": every_row_ms,
             "ms_per_step_dense_gradients": dense_ms,
             "ms_per_step_f32_chains": f32_ms,
             "ms_per_step_f32_chains_dense_gradients": f32_dense_ms,
-            "side_measurements": "after the timed region, a few steps each, not part of value: _dense_gradients = every "
-                                 "backward product over every nonzero and row, as the reference multiplies; _f32_chains "
+            "side_measurements": "after the timed region, a few steps each, not part of value: _every_row = every row of "
+                                 "every activation formed, backward products over the rows and nonzeros that can be "
+                                 "nonzero; _dense_gradients = every "
+                                 "product over every nonzero and row, as the reference multiplies; _f32_chains "
                                  "= a second engine with every dense product on exact fp32 MFMA chains",
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,
         }
         if ev_used:
-            ms = [s.elapsed_time(e) for s, e in ev_used]
+            ms = [s.elapsed_time(e) for s, e, _, _ in ev_used]
             avg = sum(ms) / len(ms) * 1e-3
-            bytes_ = algorithmic_bytes(a.nnz, a.n_rows, args.hidden)
+            k_nnz, k_rows = ev_used[0][2], ev_used[0][3]          # the matrix the timed launches multiplied
+            bytes_ = algorithmic_bytes(k_nnz, k_rows, args.hidden)
             # HBM traffic of this kernel comes from rocprofv3 --pmc passes (FETCH_SIZE,
             # WRITE_SIZE; separate runs of tools/spmm_bench.py on the same matrix and
             # width), folded into bytes in profiles/spmm_hbm_traffic.json.  It is NOT
@@ -593,8 +628,10 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")) as fh:
                     rec = json.load(fh)
+                if field_info is not None:
+                    rec = rec.get("labelled_field", {})
                 if rec.get("scale") == scale and rec.get("width") == args.hidden and world == 1 and \
-                        rec.get("edge_factor", 8) == args.edge_factor:
+                        rec.get("edge_factor", 8) == args.edge_factor and rec.get("nnz", k_nnz) == k_nnz:
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_source = "static: profiles/spmm_hbm_traffic.json <- " + str(rec.get("source"))
                     l2_hit = rec.get("l2_hit_rate")
@@ -606,16 +643,19 @@ def main():
                 pass
             result["roofline"] = {
                 "bound": "hbm",
-                "kernel": "spmm_chunk_kernel<4,8> + its fix-up pass spmm_fixup_kernel<4> (A_hat x [N,%d] fp32)"
-                          % args.hidden,
+                "kernel": "spmm_chunk_kernel<4,8> + its fix-up pass spmm_fixup_kernel<4> (%s x [%s,%d] fp32)"
+                          % ((("A_hat", "N") if field_info is None else
+                              ("A_hat[rows of H', rows of P1]", "rows of P1")) + (args.hidden,)),
+                "matrix_rows": k_rows, "matrix_nnz": k_nnz,
                 "achieved": bytes_ / avg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": bytes_ / avg / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_is": "bytes leaving the L2s per launch (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included",
                 "hbm_bytes_physical": None, "hbm_bytes_physical_note": physical_note, "l2_hit_rate": l2_hit,
                 "timed_window": "HIP events on the launch stream around the main pass and the fix-up pass",
                 "algorithmic_bytes_per_launch": bytes_, "avg_launch_ms": avg * 1e3,
-                "launches_timed": len(ms), "kernel_nnzF_per_s": a.nnz * args.hidden / avg,
-                "compulsory_bytes_per_launch": 8 * a.nnz + 8 * a.n_rows * args.hidden + 8 * (a.n_rows + 1),
+                "launches_timed": len(ms), "kernel_nnzF_per_s": k_nnz * args.hidden / avg,
+                "compulsory_bytes_per_launch": 8 * k_nnz + 4 * (k_rows + (field_info["rows_of_P1"] if field_info else
+                                                                         a.n_rows)) * args.hidden + 8 * (k_rows + 1),
             }
         if gemm_ev:
             split = ops.dense_arith() == 0

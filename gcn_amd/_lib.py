@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GCNX_LIB overrides the path (kernel-variant experiments during development)
 LIB_PATH = os.environ.get("GCNX_LIB") or os.path.join(_HERE, "lib", "libgcnhip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SPMM_STATIC_SCRATCH_BYTES = 32 << 20   # GCNX_SPMM_STATIC_SCRATCH_BYTES of include/gcnx.h
 
 OK = 0
@@ -73,6 +73,8 @@ SIGNATURES = {
     "gcnx_spmm_signs_supported": (_int, [_i32]),
     "gcnx_spmm_csr_signs_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32, _int,
                                        _p, _p, _i64, _p, _sz, _p]),
+    "gcnx_spmm_csr_rows_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _f32, _int,
+                                      _p, _p, _p, _i64, _p, _sz, _p]),
     "gcnx_spmm_factored_supported": (_int, [_i32, _i32]),
     "gcnx_spmm_csr_factored_f32": (_int, [_csr_p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _int,
                                           _i32, _f32, _p, _i64, _i32, _p, _sz, _p]),

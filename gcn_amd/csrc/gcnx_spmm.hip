@@ -98,6 +98,9 @@ struct SpmmArgs {
   uint64_t drop_offset;
   int64_t drop_ld;
   int64_t drop_col0;
+  // nullable: output row r draws the mask of row drop_rows[r] (the output holds a
+  // subset of the rows of the activation the mask is defined on)
+  const int32_t *drop_rows;
   // nullable (wide kernel only): sign pattern of the stored output, bit (c % 32) of
   // word sign_bits[r * ld_sign + c / 32] set <=> stored element (r, c) > 0
   uint32_t *sign_bits;
@@ -126,7 +129,8 @@ __device__ __forceinline__ typename vec_of<VEC>::type epilogue_store(const SpmmA
   if (a.beta != 0.0f) out += vload<VEC>(dst) * a.beta;
   if (a.relu) out = vmax0<VEC>(out);
   if (a.drop_keep < 1.0f) {
-    const uint64_t e0 = a.drop_offset + (uint64_t)r * (uint64_t)a.drop_ld + (uint64_t)(a.drop_col0 + col0);
+    const uint64_t dr = a.drop_rows ? (uint64_t)a.drop_rows[r] : (uint64_t)r;
+    const uint64_t e0 = a.drop_offset + dr * (uint64_t)a.drop_ld + (uint64_t)(a.drop_col0 + col0);
     const float inv = 1.0f / a.drop_keep;
     if constexpr (VEC == 4) {
       // the host checked that e0 is a multiple of 4: one Philox block per store
@@ -1156,8 +1160,8 @@ __global__ void spmm_empty_kernel(const SpmmArgs a) {
   float out = a.beta != 0.0f ? *dst * a.beta : 0.0f;
   if (a.relu && out < 0.0f) out = 0.0f;   // a NaN stays a NaN
   if (a.drop_keep < 1.0f) {
-    const uint64_t e0 = a.drop_offset + (uint64_t)(i / a.width) * (uint64_t)a.drop_ld +
-                        (uint64_t)(a.drop_col0 + (i % a.width));
+    const uint64_t dr = a.drop_rows ? (uint64_t)a.drop_rows[i / a.width] : (uint64_t)(i / a.width);
+    const uint64_t e0 = a.drop_offset + dr * (uint64_t)a.drop_ld + (uint64_t)(a.drop_col0 + (i % a.width));
     const philox4 rnd = philox4x32_10(e0 >> 2, 0ull, a.drop_seed);
     out = ((float)(rnd.v[e0 & 3] >> 8) * (1.0f / 16777216.0f) < a.drop_keep) ? out / a.drop_keep : 0.0f;
   }
@@ -1262,8 +1266,8 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
                      const float *B2, int64_t ldb2, int64_t split_col, float *C, int64_t ldc,
                      int32_t width, float alpha, float beta, const uint8_t *val_mask,
                      const int64_t *mask_index, float mask_scale, int fuse_relu,
-                     const gcnx_dropout *out_dropout, uint32_t *sign_bits, int64_t ld_sign, void *ws,
-                     size_t ws_bytes, void *stream);
+                     const gcnx_dropout *out_dropout, const int32_t *drop_rows, uint32_t *sign_bits,
+                     int64_t ld_sign, void *ws, size_t ws_bytes, void *stream);
 
 extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
                                        int64_t ldb, const float *B2, int64_t ldb2,
@@ -1273,7 +1277,7 @@ extern "C" int gcnx_spmm_csr_split_f32(const gcnx_csr *a, const int32_t *chunk_r
                                        const gcnx_dropout *out_dropout, void *ws, size_t ws_bytes,
                                        void *stream) {
   return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, val_mask, mask_index,
-                   mask_scale, fuse_relu, out_dropout, nullptr, 0, ws, ws_bytes, stream);
+                   mask_scale, fuse_relu, out_dropout, nullptr, nullptr, 0, ws, ws_bytes, stream);
 }
 
 extern "C" int gcnx_spmm_signs_supported(int32_t width) { return (width >= 32 && width % 32 == 0) ? 1 : 0; }
@@ -1287,15 +1291,27 @@ extern "C" int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_r
   GCNX_REQUIRE(sign_bits && ld_words * 32 >= width && gcnx_spmm_signs_supported(width), GCNX_ERR_UNSUPPORTED,
                "spmm_signs: needs width %% 32 == 0 and ld_words * 32 >= width");
   return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, nullptr, nullptr,
-                   1.0f, fuse_relu, out_dropout, sign_bits, ld_words, ws, ws_bytes, stream);
+                   1.0f, fuse_relu, out_dropout, nullptr, sign_bits, ld_words, ws, ws_bytes, stream);
+}
+
+extern "C" int gcnx_spmm_csr_rows_f32(const gcnx_csr *a, const int32_t *chunk_row, const float *B,
+                                      int64_t ldb, const float *B2, int64_t ldb2, int64_t split_col,
+                                      float *C, int64_t ldc, int32_t width, float alpha, float beta,
+                                      int fuse_relu, const gcnx_dropout *out_dropout,
+                                      const int32_t *dropout_row_ids, uint32_t *sign_bits, int64_t ld_words,
+                                      void *ws, size_t ws_bytes, void *stream) {
+  GCNX_REQUIRE(!sign_bits || (ld_words * 32 >= width && gcnx_spmm_signs_supported(width)), GCNX_ERR_UNSUPPORTED,
+               "spmm_rows: sign words need width %% 32 == 0 and ld_words * 32 >= width");
+  return spmm_impl(a, chunk_row, B, ldb, B2, ldb2, split_col, C, ldc, width, alpha, beta, nullptr, nullptr,
+                   1.0f, fuse_relu, out_dropout, dropout_row_ids, sign_bits, ld_words, ws, ws_bytes, stream);
 }
 
 static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B, int64_t ldb,
                      const float *B2, int64_t ldb2, int64_t split_col, float *C, int64_t ldc,
                      int32_t width, float alpha, float beta, const uint8_t *val_mask,
                      const int64_t *mask_index, float mask_scale, int fuse_relu,
-                     const gcnx_dropout *out_dropout, uint32_t *sign_bits, int64_t ld_sign, void *ws,
-                     size_t ws_bytes, void *stream) {
+                     const gcnx_dropout *out_dropout, const int32_t *drop_rows, uint32_t *sign_bits,
+                     int64_t ld_sign, void *ws, size_t ws_bytes, void *stream) {
   GCNX_REQUIRE(a, GCNX_ERR_INVALID_ARG, "spmm: null matrix");
   GCNX_REQUIRE(a->n_rows >= 0 && a->n_cols >= 0 && a->nnz >= 0 && width >= 0,
                GCNX_ERR_INVALID_ARG, "spmm: negative size");
@@ -1338,6 +1354,7 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
   k.drop_offset = 0;
   k.drop_ld = 0;
   k.drop_col0 = 0;
+  k.drop_rows = nullptr;
   k.sign_bits = sign_bits;
   k.ld_sign = ld_sign;
   bool drop_vec_ok = true;
@@ -1349,6 +1366,7 @@ static int spmm_impl(const gcnx_csr *a, const int32_t *chunk_row, const float *B
     k.drop_offset = out_dropout->offset;
     k.drop_ld = out_dropout->ld;
     k.drop_col0 = out_dropout->col0;
+    k.drop_rows = drop_rows;
     drop_vec_ok = (out_dropout->offset % 4 == 0) && (out_dropout->ld % 4 == 0) && (out_dropout->col0 % 4 == 0);
   }
 
@@ -1512,7 +1530,7 @@ extern "C" int gcnx_spmm_csr_static_f32(const gcnx_csr *a, const int32_t *chunk_
   const int rc = static_scratch(&ws);
   if (rc != GCNX_OK) return rc;
   return spmm_impl(a, chunk_row, B, ldb, nullptr, 0, a->n_cols, C, ldc, width, alpha, beta, val_mask, mask_index,
-                   mask_scale, fuse_relu, nullptr, nullptr, 0, ws, (size_t)GCNX_SPMM_STATIC_SCRATCH_BYTES, stream);
+                   mask_scale, fuse_relu, nullptr, nullptr, nullptr, 0, ws, (size_t)GCNX_SPMM_STATIC_SCRATCH_BYTES, stream);
 }
 
 #ifndef GCNX_FACTORED_U

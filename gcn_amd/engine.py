@@ -59,7 +59,8 @@ class FullBatchGCN(object):
                  w1, w2, a_bwd_local=None, row_begin=0, n_global=None, lr=0.01, weight_decay=5e-4,
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
                  kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None,
-                 sparse_loss_gradient=True, overlap_class_exchange=True, pack_gate_operands=True):
+                 sparse_loss_gradient=True, overlap_class_exchange=True, pack_gate_operands=True,
+                 labelled_field_only=True):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -89,7 +90,21 @@ class FullBatchGCN(object):
         compute stream; a row's sum is then grouped (local terms, then halo terms)
         instead of running in column order, so one rank and several agree to fp32
         rounding, not to the bit (False: one product after the exchange, bitwise
-        independent of the rank count)."""
+        independent of the rank count).
+        ``labelled_field_only`` (one rank, reference order, with
+        ``sparse_loss_gradient``): a training step forms only what its loss, its
+        accuracy and its weight update depend on.  The masked loss reads the logits
+        of the labelled rows; those read H' at the nodes with a labelled neighbour
+        (N1); those read P1 at the nodes with a neighbour in N1 (N2).  The step then
+        runs on three sets of rows stored next to each other -- X', P1, dP1 over N2;
+        H', P2, dP2 over N1; Z, dZ over the labelled rows -- through the matrices
+        A_hat[N1, N2] and A_hat[labelled, N1] and their transposes (built once, the
+        label mask being fixed).  Every sum that is formed has the terms, in the order,
+        of the full computation (dropout masks are drawn by node id), so loss,
+        accuracy and weights agree with it to the rounding of where a long row is cut
+        into partial sums; the rows left out are the ones no output of the step
+        depends on.  ``evaluate()`` still forms every row.  False: every row of every
+        activation, as the reference does."""
         self.k = kernels if kernels is not None else _hip_ops
         self.comm = comm
         self.a = a_local
@@ -211,6 +226,9 @@ class FullBatchGCN(object):
                 self._gate_records_halo = torch.zeros((nh, 32), dtype=torch.float32, device=self.dev)
                 self.dp2_halo = self._gate_records_halo[:, :self.c]
                 self.hbits_halo = self._gate_records_halo.view(torch.int32)[:, self.c:self.c + words]
+        self.field = None
+        if labelled_field_only:
+            self._setup_labelled_field(pack_gate_operands)
 
     def _hint_forward_matrix(self):
         width = self.f if self.order == "aggregate_first" else self.h
@@ -432,10 +450,139 @@ class FullBatchGCN(object):
         self.hb_c = torch.empty((m, self.h), dtype=torch.float32, device=self.dev)
         self.hb = None                              # the full-height buffer is not needed
 
+    # ------------------------------------ the step over the labelled rows' field only
+    def _setup_labelled_field(self, pack_records):
+        """``self.field``: the row sets, matrices and buffers of the training step
+        restricted to what the labelled rows depend on (see ``labelled_field_only``),
+        or None when it does not apply or would not pay."""
+        k = self.k
+        need = ("csr_transpose", "csr_keep_rows", "csr_compact_rows", "csr_filter_columns", "gather_rows")
+        if self.world != 1 or self.order != "reference" or self.at_dz_c is None or self.at_wide is None or \
+                self.keep_masks or any(not hasattr(k, n) for n in need):
+            return
+        if self.keep <= 0.0:
+            return
+        dev, c, h = self.dev, self.c, self.h
+        e = lambda *sh, **kw: torch.empty(sh, dtype=kw.get("dtype", torch.float32), device=dev)
+        fd = type("LabelledField", (), {})()
+        lab = torch.nonzero(self.ymask != 0).view(-1)
+        fd.lab_rows = lab.to(torch.int32).contiguous()
+        fd.rows1 = self.dz_rows                      # N1: nodes some labelled row reads
+        n_l, n1 = int(lab.numel()), int(self.dz_rows.numel())
+        if n_l == 0:
+            return
+        # A_hat[labelled, N1]: at_dz_c is (A_hat^T)[N1, labelled columns], rows next to each other
+        t = k.csr_transpose(self.at_dz_c)           # [n, n1]; only labelled rows hold nonzeros
+        fd.a_z = k.csr_keep_rows(t, fd.lab_rows)    # [n_l, n1]
+        fd.a_zt = k.csr_transpose(fd.a_z)           # [n1, n_l]
+        # N2: the nodes some row of N1 reads (the rows of at_wide that hold a nonzero)
+        if self.at_wide_c is not None:
+            src, fd.rows2, fd.x2 = self.at_wide_c, self.hb_rows, self.x_c
+        else:
+            sub, rows = k.csr_compact_rows(self.at_wide)
+            if 0 < int(sub.n_rows) <= (self.n_loc * 7) // 10 and (self.keep >= 1.0 or
+                                                                  hasattr(k, "dropout_rows_philox")):
+                src, fd.rows2 = sub, rows.to(dev)
+                fd.x2 = torch.empty((int(sub.n_rows), self.f), dtype=torch.float32, device=dev)
+                k.gather_rows(self.x, fd.rows2, fd.x2)
+            else:
+                src, fd.rows2, fd.x2 = self.at_wide, None, self.x
+        n2 = int(src.n_rows)
+        # dropout(X) over N2: regenerated inside the two products that read it where their
+        # shapes are served, else stored once per step
+        fd.fuse_x = fd.xd = None
+        if self.keep < 1.0:
+            sup = getattr(k, "gemm_supports_a_dropout", None)
+            sup_t = getattr(k, "gemm_supports_a_dropout_rows_t", None)
+            fd.fuse_x = bool(sup is not None and sup(False, n2, h, self.f) and sup(True, self.f, h, n2) and
+                             (fd.rows2 is None or (sup_t is not None and sup_t(self.f, h, n2))))
+            if not fd.fuse_x:
+                fd.xd = e(n2, self.f) if fd.rows2 is not None or self.xd is None else self.xd
+        t = k.csr_transpose(src)                     # [n, n2]; only rows of N1 hold nonzeros
+        fd.a_h = k.csr_keep_rows(t, fd.rows1)        # A_hat[N1, N2]
+        del t
+        fd.a_ht = k.csr_transpose(fd.a_h)            # (A_hat^T)[N2, N1], columns numbered within N1
+        hint = getattr(fd.a_h, "set_gather_hint", None)
+        if hint is not None and h > 128 and n2 * h * 4 > (1 << 30) and fd.a_h.nnz > (1 << 24):
+            hint(h * 4)
+        fd.n_l, fd.n1, fd.n2 = n_l, n1, n2
+        fd.nnz_h, fd.nnz_z = int(fd.a_h.nnz), int(fd.a_z.nnz)
+        fd.p1 = e(n2, h)                             # X' W1 over N2
+        # dP1 over N2
+        fd.hb = self.hb_c if self.at_wide_c is not None else self.hb if fd.rows2 is None else e(n2, h)
+        fd.hd = self.hd_c                            # H' over N1
+        fd.p2 = e(n1, c)
+        fd.z, fd.dz = e(n_l, c), e(n_l, c)
+        fd.y = self.y[lab].contiguous()
+        fd.ymask = self.ymask[lab].contiguous()
+        words = h // 32
+        sup_bits = getattr(k, "spmm_supports_sign_bits", None)
+        fd.hbits = None
+        fd.dp2 = None
+        if self.factored_bwd and pack_records and c % 4 == 0 and 4 * (c + words) <= 128:
+            # the row of dP2 and the sign words of a node of N1 side by side in one
+            # 128-byte record, as in the full-height step
+            fd.records = torch.zeros((n1, 32), dtype=torch.float32, device=dev)
+            fd.dp2 = fd.records[:, :c]
+            fd.hbits = fd.records.view(torch.int32)[:, c:c + words]
+        else:
+            fd.dp2 = e(n1, c)
+            if sup_bits is not None and sup_bits(h):
+                fd.hbits = torch.empty((n1, words), dtype=torch.int32, device=dev)
+        fd.factored = bool(self.factored_bwd and fd.hbits is not None)
+        fd.g = None if fd.factored else e(n1, h)     # the gated product over N1 when it has to be stored
+        self.field = fd
+
+    def _train_step_field(self):
+        """One optimisation step over the labelled rows' field (``self.field``)."""
+        k, fd = self.k, self.field
+        keep = self.keep
+        off = self.step_no * (1 << 44)
+        xkey = (keep, self.seed * 2 + 1, off + self.row_begin * self.f) if keep < 1.0 else None
+        xrows = fd.rows2
+        xin = fd.x2
+        if xkey is not None and not fd.fuse_x:
+            if xrows is not None:
+                k.dropout_rows_philox(fd.x2, xrows, xkey[0], xkey[1], xkey[2], out=fd.xd)
+            else:
+                k.dropout_philox(fd.x2.view(-1), xkey[0], xkey[1], xkey[2], out=fd.xd.view(-1))
+            xin, xkey = fd.xd, None
+        if xkey is not None:
+            k.gemm(xin, self.w1, out=fd.p1, a_dropout=xkey, a_dropout_rows=xrows)
+        else:
+            k.gemm(xin, self.w1, out=fd.p1)
+        drop = (keep, self.seed * 2 + 2, off + self.row_begin * self.h, self.h, 0) if keep < 1.0 else None
+        kw = {"sign_bits": fd.hbits} if fd.hbits is not None else {}
+        k.spmm(fd.a_h, fd.p1, out=fd.hd, relu=True, dropout=drop, dropout_rows=fd.rows1 if drop is not None else None,
+               **kw)
+        k.gemm(fd.hd, self.w2, out=fd.p2)
+        k.spmm(fd.a_z, fd.p2, out=fd.z)
+        out, _ = k.masked_softmax_xent(fd.z, fd.y, fd.ymask, want_grad=True, mask_total=self.mask_total,
+                                       grad_out=fd.dz)
+        k.spmm(fd.a_zt, fd.dz, out=fd.dp2)                                   # A^T dZ over N1
+        k.gemm(fd.hd, fd.dp2, trans_a=True, out=self.g2)                      # H'^T dP2
+        scale = 1.0 / keep
+        if fd.factored:
+            k.spmm_factored(fd.a_ht, fd.dp2, self.w2, fd.hbits, gate_scale=scale, trans_w=True, out=fd.hb)
+        else:
+            if fd.hbits is not None:
+                k.gemm(fd.dp2, self.w2, trans_b=True, out=fd.g, gate_bits=fd.hbits, gate_scale=scale)
+            else:
+                k.gemm(fd.dp2, self.w2, trans_b=True, out=fd.g, gate=fd.hd, gate_scale=scale)
+            k.spmm(fd.a_ht, fd.g, out=fd.hb)
+        if xkey is not None:
+            k.gemm(xin, fd.hb, trans_a=True, out=self.g1, a_dropout=xkey, a_dropout_rows=xrows)
+        else:
+            k.gemm(xin, fd.hb, trans_a=True, out=self.g1)
+        k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)
+        k.adam_step(self.w2, self.g2, self.m2, self.v2, self.lr, self.step_no)
+        return out
+
     def use_dense_gradients(self):
         """From now on every backward product runs over every nonzero and row, as
         with ``sparse_loss_gradient=False`` (for measuring the two forms in one
         process; not reversible)."""
+        self.field = None
         self.at_dz = self.at_dz_c = self.dz_rows = self.p1_c = self.ax_c = None
         self.at_wide = self.at_wide_c = self.hb_rows = self.x_c = self.hb_c = None
         if self.hit_plan is not None and getattr(self, "_gate_records_halo", None) is not None:
@@ -707,6 +854,8 @@ class FullBatchGCN(object):
             raise RuntimeError("the label mask was modified after the engine was set up; its backward "
                                "sub-matrices and exchanges are derived from it: build a new engine")
         self.step_no += 1
+        if self.field is not None:
+            return self._train_step_field()
         xin, hin, xdrop = self.forward(train=True)
         out = self.loss(want_grad=True)
         keep = self.keep
@@ -820,7 +969,11 @@ class FullBatchGCN(object):
         in the reference order; the aggregate-first order has no hidden-width
         backward SpMM).  ``nnz_loss_gradient_global`` / ``nnz_backward_global``:
         the nonzeros the products A^T dZ and A^T d(A P1) actually multiply, summed
-        over the ranks (loss_gradient_nnz(), backward_nnz(); default: all of them)."""
+        over the ranks (loss_gradient_nnz(), backward_nnz(); default: all of them).
+        A step over the labelled rows' field multiplies the nonzeros of A_hat[N1, N2]
+        twice at hidden width and those of A_hat[labelled, N1] twice at class width."""
+        if self.field is not None:
+            return 2 * (self.field.nnz_h * self.h + self.field.nnz_z * self.c)
         nz = nnz_global if nnz_loss_gradient_global is None else nnz_loss_gradient_global
         nb = nnz_global if nnz_backward_global is None else nnz_backward_global
         if self.order == "aggregate_first":

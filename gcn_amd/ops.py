@@ -30,7 +30,7 @@ def _check_dense(t, name):
 
 # ------------------------------------------------------------------------ SpMM
 def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=False, b2=None,
-         dropout=None, sign_bits=None):
+         dropout=None, sign_bits=None, dropout_rows=None):
     """``out = act(alpha * A' @ b + beta * out)`` with ``A`` a :class:`Csr`.
     ``mask`` (uint8, in the order of the tuple ``A`` was built from) applies
     sparse dropout to the values on the fly.  Replaces ``dot(x, y, sparse=True)``
@@ -41,7 +41,10 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
     the epilogue (element (r, c) has Philox index offset + r*ld + col0 + c).
     ``sign_bits`` (int32 [n_rows, width / 32]) also receives the sign pattern of
     the stored output, the layout :func:`pack_sign_bits` writes
-    (:func:`spmm_supports_sign_bits`)."""
+    (:func:`spmm_supports_sign_bits`).  ``dropout_rows`` (int32 [n_rows]): output
+    row r draws the dropout mask of row ``dropout_rows[r]`` instead of r -- for a
+    matrix that holds a subset of the rows of A_hat next to each other
+    (gcnx_spmm_csr_rows_f32)."""
     lib = _lib.load()
     _check_dense(b, "b")
     rows_b2 = 0
@@ -73,20 +76,39 @@ def spmm(a, b, out=None, alpha=1.0, beta=0.0, mask=None, mask_scale=1.0, relu=Fa
         keep, seed, offset, ld, col0 = dropout
         drop = C.byref(_lib.DropoutStruct(float(keep), int(seed) & (2 ** 64 - 1), int(offset), int(ld),
                                           int(col0)))
+    if dropout_rows is not None and drop is None:
+        dropout_rows = None
+    if dropout_rows is not None:
+        dr = dropout_rows
+        if mask is not None or dr.dtype != torch.int32 or dr.dim() != 1 or dr.numel() != a.n_rows or \
+                not dr.is_contiguous() or dr.device != a.device:
+            raise ValueError("dropout_rows: contiguous int32 [n_rows] on A's device, no value mask")
     if sign_bits is not None:
         sb = sign_bits
         if mask is not None or sb.dtype != torch.int32 or sb.dim() != 2 or sb.shape[0] != a.n_rows or \
                 sb.shape[1] * 32 < width or sb.stride(1) != 1 or sb.device != a.device or \
                 not spmm_supports_sign_bits(width):
             raise ValueError("sign_bits: int32 [n_rows, width / 32] on A's device, width % 32 == 0, no mask")
+        if dropout_rows is None:
+            with torch.cuda.device(a.device):
+                need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
+                ws = WORKSPACE.get(need, a.device)
+                _lib.check(lib.gcnx_spmm_csr_signs_f32(
+                    a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
+                    _ptr(b2 if rows_b2 else None), b2.stride(0) if rows_b2 else 0, b.shape[0],
+                    _ptr(out), out.stride(0), width, float(alpha), float(beta), 1 if relu else 0, drop,
+                    _ptr(sb), sb.stride(0), _ptr(ws), ws.numel(), _stream()))
+            return out
+    if dropout_rows is not None:
         with torch.cuda.device(a.device):
             need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
             ws = WORKSPACE.get(need, a.device)
-            _lib.check(lib.gcnx_spmm_csr_signs_f32(
+            _lib.check(lib.gcnx_spmm_csr_rows_f32(
                 a.struct_ref(), _ptr(a.chunk_row), _ptr(b), b.stride(0),
                 _ptr(b2 if rows_b2 else None), b2.stride(0) if rows_b2 else 0, b.shape[0],
                 _ptr(out), out.stride(0), width, float(alpha), float(beta), 1 if relu else 0, drop,
-                _ptr(sb), sb.stride(0), _ptr(ws), ws.numel(), _stream()))
+                _ptr(dropout_rows), _ptr(sign_bits), sign_bits.stride(0) if sign_bits is not None else 0,
+                _ptr(ws), ws.numel(), _stream()))
         return out
     with torch.cuda.device(a.device):
         need = lib.gcnx_spmm_workspace_bytes(a.struct_ref(), width)
@@ -609,6 +631,18 @@ def csr_compact_rows(a):
     """``(sub, rows)``: ``a`` without its empty rows and the int32 ids of the rows kept
     (Csr.compact_rows)."""
     return a.compact_rows()
+
+
+def csr_keep_rows(a, rows):
+    """``a`` restricted to the rows ``rows`` (ascending ids; every row left out must be
+    empty), stored next to each other (Csr.keep_rows)."""
+    return a.keep_rows(rows)
+
+
+def csr_transpose(a):
+    """A fresh exact transpose of ``a`` (Csr.transpose without the cache): set-up of
+    derived matrices."""
+    return a.transpose(cache=False)
 
 
 def philox_uniform(shape, lo, hi, seed, offset, device):

@@ -183,6 +183,21 @@ class Csr(object):
         sub = Csr(int(rows.numel()), self.n_cols, row_ptr, self.col_idx, self.val, self.input_index)
         return sub, rows.to(torch.int32).contiguous()
 
+    def keep_rows(self, rows):
+        """The matrix of the rows ``rows`` (ascending ids, int32 / int64 tensor) stored
+        next to each other, for a selection that leaves out EMPTY rows only -- checked;
+        unlike :meth:`compact_rows` the selection may keep empty rows (they stay, as
+        zero rows of every product).  Shares the column and value arrays."""
+        r = rows.to(device=self.device, dtype=torch.int64)
+        if r.numel() and (int(r.min()) < 0 or int(r.max()) >= self.n_rows or
+                          (r.numel() > 1 and bool((r[1:] <= r[:-1]).any()))):
+            raise ValueError("rows must be ascending row ids of the matrix")
+        kept = int((self.row_ptr[r + 1] - self.row_ptr[r]).sum().item()) if r.numel() else 0
+        if kept != self.nnz:
+            raise ValueError("keep_rows: a row that is left out holds nonzeros (%d of %d kept)" % (kept, self.nnz))
+        row_ptr = torch.cat([self.row_ptr[r], self.row_ptr[-1:]]).contiguous()
+        return Csr(int(r.numel()), self.n_cols, row_ptr, self.col_idx, self.val, self.input_index)
+
     # ---------------------------------------------------------------- builders
     @classmethod
     def from_coo(cls, rows, cols, vals, shape, device="cuda", coords=None):
@@ -245,18 +260,20 @@ class Csr(object):
         return cls.from_coo(m.row, m.col, m.data, m.shape, device)
 
     # --------------------------------------------------------------- transpose
-    def transpose(self):
+    def transpose(self, cache=True):
         """Exact transpose (cached).  Its ``input_index`` still refers to the
         tuple this matrix was built from, so a dropout mask drawn for the
-        forward product can be reused by the backward one."""
-        if self._t is not None:
+        forward product can be reused by the backward one.  ``cache=False``: a
+        fresh matrix that neither is remembered by this one nor remembers it, and
+        carries no ``input_index`` (set-up of derived matrices)."""
+        if cache and self._t is not None:
             return self._t
         lib = _lib.load()
         dev = self.device
         t_row_ptr = torch.empty(self.n_cols + 1, dtype=torch.int64, device=dev)
         t_col_idx = torch.empty(self.nnz, dtype=torch.int32, device=dev)
         t_val = torch.empty(self.nnz, dtype=torch.float32, device=dev)
-        t_perm = torch.empty(self.nnz, dtype=torch.int64, device=dev)
+        t_perm = torch.empty(self.nnz, dtype=torch.int64, device=dev) if cache else None
         with torch.cuda.device(dev):
             need = lib.gcnx_csr_transpose_workspace_bytes(self.n_rows, self.n_cols, self.nnz)
             ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
@@ -264,6 +281,8 @@ class Csr(object):
                                               _ptr(t_val), _ptr(t_perm), _ptr(ws), ws.numel(),
                                               _stream()))
         del ws
+        if not cache:
+            return Csr(self.n_cols, self.n_rows, t_row_ptr, t_col_idx, t_val, None)
         idx = self.input_index[t_perm] if self.input_index is not None else t_perm
         t = Csr(self.n_cols, self.n_rows, t_row_ptr, t_col_idx, t_val, idx)
         t._t = self

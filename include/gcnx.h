@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GCNX_ABI_VERSION 4
+#define GCNX_ABI_VERSION 5
 
 typedef enum gcnx_status {
   GCNX_OK = 0,
@@ -214,6 +214,25 @@ int gcnx_spmm_csr_signs_f32(const gcnx_csr *a, const int32_t *chunk_row,
                             int fuse_relu, const gcnx_dropout *out_dropout,
                             uint32_t *sign_bits, int64_t ld_words, void *ws,
                             size_t ws_bytes, void *stream);
+
+/* gcnx_spmm_csr_signs_f32 for an output that holds a SUBSET of the rows of the
+ * activation the dropout mask is defined on: `a` has one row per output row
+ * (e.g. the rows of A_hat that some later product actually reads, stored next to
+ * each other), and output row r draws the mask of activation row
+ * dropout_row_ids[r] -- element (r, c) is kept iff the Philox uniform of
+ * (seed, offset + dropout_row_ids[r] * ld + col0 + c) is < keep -- so the rows
+ * come out exactly as the full product would have produced them.
+ * dropout_row_ids == NULL: as gcnx_spmm_csr_signs_f32.  sign_bits is nullable
+ * here (any width then).  No counterpart in the reference, which always forms
+ * every row (gcn/layers.py:203-226). */
+int gcnx_spmm_csr_rows_f32(const gcnx_csr *a, const int32_t *chunk_row,
+                           const float *B, int64_t ldb, const float *B2,
+                           int64_t ldb2, int64_t split_col, float *C,
+                           int64_t ldc, int32_t width, float alpha, float beta,
+                           int fuse_relu, const gcnx_dropout *out_dropout,
+                           const int32_t *dropout_row_ids,
+                           uint32_t *sign_bits /* nullable */, int64_t ld_words,
+                           void *ws, size_t ws_bytes, void *stream);
 
 /* SpMM with a FACTORED dense operand:  C = A * G  where row c of G is never
  * stored but formed for every nonzero that references it,

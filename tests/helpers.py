@@ -104,6 +104,21 @@ class OracleKernels(object):
         out.n_rows = int(len(rows))
         return out, self.torch.from_numpy(rows.astype(np.int32))
 
+    def csr_keep_rows(self, a, rows):
+        """numpy counterpart of gcn_amd.sparse.Csr.keep_rows."""
+        import copy
+        r = np.asarray(rows.numpy() if hasattr(rows, "numpy") else rows).astype(np.int64)
+        assert int((a.row_ptr[r + 1] - a.row_ptr[r]).sum()) == a.nnz
+        out = copy.copy(a)
+        out.row_ptr = np.concatenate([a.row_ptr[r], a.row_ptr[-1:]]).astype(np.int64)
+        out.n_rows = int(len(r))
+        return out
+
+    def csr_transpose(self, a):
+        import scipy.sparse as sp
+        m = sp.csr_matrix((a.val, a.col_idx, a.row_ptr), shape=(a.n_rows, a.n_cols))
+        return CpuCsr(m.T.tocsr())
+
     def gather_rows(self, src, idx, out):
         out.copy_(src[idx.long()])
         return out
@@ -115,7 +130,8 @@ class OracleKernels(object):
     def spmm_supports_sign_bits(self, width):
         return width % 32 == 0
 
-    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, sign_bits=None, alpha=1.0, beta=0.0, **kw):
+    def spmm(self, a, b, out=None, relu=False, b2=None, dropout=None, sign_bits=None, alpha=1.0, beta=0.0,
+             dropout_rows=None, **kw):
         if b2 is not None:
             b = self.torch.cat([b, b2], 0)
         r = self.o.spmm_csr(a.row_ptr, a.col_idx, a.val, b.contiguous().numpy())
@@ -127,7 +143,8 @@ class OracleKernels(object):
             r = np.maximum(r, 0)
         if dropout is not None and dropout[0] < 1.0:
             keep, seed, offset, ld, col0 = dropout
-            rows = np.arange(r.shape[0], dtype=np.uint64)[:, None]
+            rows = np.arange(r.shape[0], dtype=np.uint64)[:, None] if dropout_rows is None else \
+                dropout_rows.numpy().astype(np.uint64)[:, None]
             cols = np.arange(r.shape[1], dtype=np.uint64)[None, :]
             idx = np.uint64(offset) + rows * np.uint64(ld) + np.uint64(col0) + cols
             m = self.o.bernoulli_mask_at(idx, keep, seed)

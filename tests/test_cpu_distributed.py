@@ -314,3 +314,78 @@ def test_overlapped_and_blocking_class_exchange_agree(tmp_path):
     z_bl = np.concatenate([np.load(os.path.join(out, "w2_r%d_bl.npz" % r))["z"] for r in range(2)])
     np.testing.assert_allclose(z_ov, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
     np.testing.assert_allclose(z_bl, one["z"], rtol=0, atol=1e-5 * np.abs(one["z"]).max())
+
+
+@pytest.mark.parametrize("hidden,classes,dropout,label_rate,scale,no_self_loop", [
+    (64, 16, 0.5, 0.02, 9, False),      # factored backward, operands in records, N2 clearly smaller than N
+    (64, 16, 0.0, 0.02, 9, False),      # no dropout at all
+    (16, 5, 0.5, 0.03, 8, False),       # no sign words at this width: gate read from H'
+    (32, 5, 0.5, 0.03, 8, False),       # sign words, bit-gated product then SpMM
+    (64, 16, 0.5, 0.08, 8, False),      # N2 is most of the graph: X and dP1 keep their full height
+    (64, 16, 0.5, 0.03, 8, True),       # a labelled node whose row of A_hat is empty: a zero row of logits
+    (64, 16, 0.5, 0.02, 9, "stored-dropout"),     # products that cannot regenerate dropout(X): stored over N2
+    (64, 16, 0.5, 0.08, 8, "stored-dropout")])    # ... and over every row
+def test_labelled_field_step_matches_full_step(hidden, classes, dropout, label_rate, scale, no_self_loop):
+    """The training step over the labelled rows' field (rows of N2 / N1 / the labelled
+    set stored next to each other, A_hat[N1, N2] and A_hat[labelled, N1]) against the
+    step that forms every row: same losses, accuracies, gradients and weights to
+    rounding; the rows it does form equal the same rows of the full step."""
+    from gcn_amd import engine
+    n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(scale=scale, hidden=hidden, classes=classes,
+                                                                   label_rate=label_rate)
+    kernels = OracleKernels
+    if no_self_loop == "stored-dropout":
+        no_self_loop = False
+
+        class kernels(OracleKernels):
+            def gemm_supports_a_dropout(self, trans_a, M, N, K):
+                return False
+    if no_self_loop:
+        a_hat = a_hat.tolil()
+        victim = int(np.nonzero(lmask)[0][1])
+        a_hat[victim, :] = 0
+        a_hat[:, victim] = 0
+        a_hat = a_hat.tocsr().astype(np.float32)
+        a_hat.eliminate_zeros()
+    T = torch.from_numpy
+    mk = lambda on: engine.FullBatchGCN(
+        CpuCsr(a_hat), T(x.copy()), T(labels.copy()), T(lmask.copy()), int(lmask.sum()), hidden, classes, T(w1), T(w2),
+        seed=5, kernels=kernels(), dropout=dropout, labelled_field_only=on)
+    field, full = mk(True), mk(False)
+    fd = field.field
+    assert fd is not None and full.field is None
+    assert (fd.xd is not None) == (kernels is not OracleKernels) == (dropout > 0 and not fd.fuse_x)
+    lab = np.nonzero(lmask)[0]
+    n1_ref = np.unique(a_hat[lab].indices)                       # columns the labelled rows read
+    n2_ref = np.unique(a_hat[n1_ref].indices)
+    assert np.array_equal(fd.lab_rows.numpy(), lab) and np.array_equal(fd.rows1.numpy(), n1_ref)
+    assert fd.n_l == len(lab) and fd.n1 == len(n1_ref)
+    if fd.rows2 is not None:
+        assert np.array_equal(fd.rows2.numpy(), n2_ref) and fd.n2 == len(n2_ref) < n
+    else:
+        assert fd.n2 == n and len(n2_ref) > (n * 7) // 10
+    assert (fd.rows2 is None) == (label_rate >= 0.08)
+    assert fd.nnz_h == a_hat[n1_ref].nnz and fd.nnz_z == a_hat[lab].nnz
+    assert fd.factored == (hidden == 64 and classes == 16)
+    if fd.factored:
+        assert fd.dp2.stride(0) == 32 == fd.hbits.stride(0)
+    for step in range(3):
+        o_field, o_full = field.train_step().numpy().copy(), full.train_step().numpy().copy()
+        np.testing.assert_allclose(o_field, o_full, rtol=1e-5, atol=1e-7)
+        for name in ("g1", "g2"):
+            ref = getattr(full, name).numpy()
+            np.testing.assert_allclose(getattr(field, name).numpy(), ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+        np.testing.assert_allclose(field.w1.numpy(), full.w1.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(field.w2.numpy(), full.w2.numpy(), rtol=0, atol=2e-6)
+        # the rows the field step forms are the same rows of the full step
+        np.testing.assert_allclose(fd.z.numpy(), full.z.numpy()[lab], rtol=0, atol=1e-5 * np.abs(full.z.numpy()).max())
+        np.testing.assert_allclose(fd.hd.numpy(), full.hd.numpy()[n1_ref], rtol=0,
+                                   atol=1e-5 * np.abs(full.hd.numpy()).max())
+    if no_self_loop:
+        assert not fd.z.numpy()[1].any()
+    # evaluation forms every row in either engine
+    np.testing.assert_allclose(field.evaluate().numpy(), full.evaluate().numpy(), rtol=1e-5, atol=1e-7)
+    # ... and an engine switched to dense gradients leaves the field
+    field.use_dense_gradients()
+    assert field.field is None
+    np.testing.assert_allclose(field.train_step().numpy(), full.train_step().numpy(), rtol=1e-5, atol=1e-7)

@@ -354,7 +354,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().gcnx_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().gcnx_abi_version() == _lib.ABI_VERSION == 5
     assert _lib.load().gcnx_spmm_chunk_nnz() == 64
     # pure host-side queries work without a GPU
     assert _lib.load().gcnx_spmm_num_chunks(1025) == 17

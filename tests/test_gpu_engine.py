@@ -71,8 +71,12 @@ def _dense_tuple(x):
     (128, 16, "reference-dense-dz", 9, 48),
     # few labelled nodes: the rows of dP2 that can be nonzero are formed next to each
     # other and H'^T dP2 sums over those rows only
+    # (in the reference order the whole step then runs over the labelled rows' field:
+    # Z at the labelled rows, H' at the rows those read, P1 at the rows those read)
     (256, 16, "reference-few-labels", 11, 128), (16, 7, "reference-few-labels", 10, 48),
-    (128, 16, "aggregate_first-few-labels", 11, 64)])
+    (128, 16, "aggregate_first-few-labels", 11, 64),
+    # ... and the same with every row of every activation formed
+    (256, 16, "reference-few-labels-every-row", 11, 128), (16, 7, "reference-few-labels-every-row", 10, 48)])
 def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
@@ -83,13 +87,23 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     w1 = (rng.uniform(-1, 1, (f, hidden)) * 0.2).astype(np.float32)
     w2 = (rng.uniform(-1, 1, (hidden, classes)) * 0.2).astype(np.float32)
     labels = np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)]
-    lmask = (rng.random_sample(n) < (0.01 if order.endswith("few-labels") else 0.2)).astype(np.uint8)
+    few = "few-labels" in order
+    every_row = order.endswith("every-row")
+    lmask = (rng.random_sample(n) < (0.01 if few else 0.2)).astype(np.uint8)
     T = lambda v: torch.from_numpy(v).to(dev)
     sparse_dz = order != "reference-dense-dz"
-    few = order.endswith("few-labels")
     order = order.split("-")[0]
     eng = env["engine"].FullBatchGCN(a, T(x), T(labels), T(lmask), int(lmask.sum()), hidden, classes,
-                                     T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz)
+                                     T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz,
+                                     labelled_field_only=not every_row)
+    lab_idx = np.nonzero(lmask)[0]
+    if every_row or order != "reference" or not sparse_dz:
+        assert eng.field is None
+    elif few:
+        # the step over the labelled rows' field, its operand records as in the full-height step
+        fd = eng.field
+        assert fd is not None and np.array_equal(fd.lab_rows.cpu().numpy(), lab_idx) and fd.n1 < n // 2
+        assert fd.factored == (hidden == 256) and (not fd.factored or fd.dp2.stride(0) == 32 == fd.hbits.stride(0))
     if hidden == 256 and classes == 16 and order == "reference":
         # the operands of the factored backward product lie side by side, one 128-byte record per node
         assert eng.factored_bwd and eng.dp2.stride(0) == 32 == eng.hbits.stride(0)
@@ -143,12 +157,16 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
         g_gpu = [N(eng.g1), N(eng.g2)]
         # (1) logits, loss and both gradients within 1e-5 of the summed terms, element by
         # element, and within 1e-5 of the largest element
-        assert_close_to_f64(N(eng.z), *y64["logits"], what="logits, step %d" % step)
+        if eng.field is not None:
+            z_gpu, z64 = N(eng.field.z), tuple(v[lab_idx] for v in y64["logits"])
+        else:
+            z_gpu, z64 = N(eng.z), y64["logits"]
+        assert_close_to_f64(z_gpu, *z64, what="logits, step %d" % step)
         assert abs(got[0] - y64["xent"][0]) <= 1e-5 * y64["xent"][1]
         for name, g in zip(("g1", "g2"), g_gpu):
             assert_close_to_f64(g, *y64[name], what="%s, step %d" % (name, step))
             assert np.abs(g - y64[name][0]).max() <= 1e-5 * np.abs(y64[name][0]).max(), (name, step)
-        assert np.abs(N(eng.z) - y64["logits"][0]).max() <= 1e-5 * np.abs(y64["logits"][0]).max()
+        assert np.abs(z_gpu - z64[0]).max() <= 1e-5 * np.abs(y64["logits"][0]).max()
         # ... and against the fp32 oracle's own loss and accuracy
         assert abs(got[0] - xent) <= 1e-5 * abs(xent) + 1e-6, (step, got[0], xent)
         assert abs(got[1] - acc) <= 1e-6
@@ -289,7 +307,8 @@ def test_degree32_shard_at_scale(env):
     labels = torch.zeros((n, 16), device=dev)
     labels.scatter_(1, cls.view(-1, 1), 1.0)
     lmask = (torch.arange(n, device=dev) % 100 == 0).to(torch.uint8)
-    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123)
+    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123,
+                                     labelled_field_only=False)
     assert eng.factored_bwd and eng.at_wide is not None and eng.at_wide.nnz < a.nnz
     w1_before = eng.w1.clone()
     out = eng.train_step().cpu().numpy()
@@ -302,6 +321,62 @@ def test_degree32_shard_at_scale(env):
     assert np.isfinite(out2).all()
     del eng
     torch.cuda.empty_cache()
+
+
+def test_labelled_field_step_at_scale(env):
+    """The benchmark's graph and widths (RMAT 2^24, degree 16, 1 % labelled): the
+    training step over the labelled rows' field against the step that forms every
+    row, from the same weights -- loss, accuracy, both gradients, the logits of the
+    labelled rows and sampled rows of H' -- and the row sets against their definition."""
+    torch, dev, ops = env["torch"], env["dev"], env["ops"]
+    torch.cuda.empty_cache()
+    a = env["rmat"].rmat_ahat(24, 8, 123, dev)
+    n = a.n_rows
+    x = ops.philox_uniform((n, 256), -1.0, 1.0, 124, 0, dev)
+    w1 = ops.philox_uniform((256, 256), -0.1, 0.1, 125, 0, dev)
+    w2 = ops.philox_uniform((256, 16), -0.15, 0.15, 125, 1 << 40, dev)
+    cls = ops.philox_uniform((n,), 0.0, 16.0, 126, 0, dev).to(torch.int64).clamp_(0, 15)
+    labels = torch.zeros((n, 16), device=dev)
+    labels.scatter_(1, cls.view(-1, 1), 1.0)
+    lmask = (torch.arange(n, device=dev) % 100 == 0).to(torch.uint8)
+    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123)
+    fd = eng.field
+    assert fd is not None and fd.factored and fd.dp2.stride(0) == 32 == fd.hbits.stride(0)
+    # N1 = the columns the labelled rows hold, N2 = the columns the rows of N1 hold
+    flag1 = torch.zeros(n, dtype=torch.bool, device=dev)
+    rows_of = torch.repeat_interleave(torch.arange(n, device=dev), a.row_ptr[1:] - a.row_ptr[:-1])
+    flag1[a.col_idx[lmask[rows_of] != 0].long()] = True
+    assert torch.equal(torch.nonzero(flag1).view(-1).to(torch.int32), fd.rows1) and fd.n1 == int(flag1.sum())
+    in1 = flag1[rows_of]
+    flag2 = torch.zeros(n, dtype=torch.bool, device=dev)
+    flag2[a.col_idx[in1].long()] = True
+    assert fd.nnz_h == int(in1.sum()) and fd.nnz_h < a.nnz
+    assert fd.rows2 is not None and torch.equal(torch.nonzero(flag2).view(-1).to(torch.int32), fd.rows2)
+    assert fd.nnz_z == int((lmask[rows_of] != 0).sum())
+    del rows_of, in1, flag1, flag2
+    out_f = eng.train_step().cpu().numpy()
+    g1_f, g2_f, z_f = eng.g1.clone(), eng.g2.clone(), fd.z.clone()
+    pick = torch.randint(0, fd.n1, (300,), generator=torch.Generator().manual_seed(5)).to(dev)
+    hd_f, hd_rows = fd.hd[pick].clone(), fd.rows1[pick].long()
+    bits_f = fd.hbits[pick].clone()
+    # the same step once more with every row formed: rewind the weights and Adam's state
+    eng.w1.copy_(w1)
+    eng.w2.copy_(w2)
+    for t in (eng.m1, eng.v1, eng.m2, eng.v2):
+        t.zero_()
+    eng.step_no = 0
+    eng.field = None
+    out_e = eng.train_step().cpu().numpy()
+    assert abs(out_f[0] - out_e[0]) <= 1e-5 * abs(out_e[0]) and abs(out_f[1] - out_e[1]) <= 1e-6
+    for got, ref in ((g1_f, eng.g1), (g2_f, eng.g2)):
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    z_e = eng.z[fd.lab_rows.long()]
+    assert float((z_f - z_e).abs().max()) <= 1e-5 * float(z_e.abs().max())
+    # rows of H' (dropout drawn by node id): same survivors, same values to rounding, same sign words
+    hd_e = eng.hd[hd_rows]
+    assert torch.equal(hd_f != 0, hd_e != 0)
+    assert float((hd_f - hd_e).abs().max()) <= 1e-5 * float(hd_e.abs().max())
+    assert torch.equal(bits_f, eng.hbits[hd_rows])
 
 
 @pytest.mark.parametrize("halo_mode,features,hidden,order", [
