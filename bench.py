@@ -557,6 +557,31 @@ def main():
         torch.cuda.empty_cache()
         note("fp32-chain side measurement done")
 
+    # Third side measurement (one GPU, reference order timed above): the same step with the
+    # first layer associated the other way, (A_hat X') W1 -- an engine option whose results
+    # agree with the reference's association to rounding, not to the bit.
+    agg_ms = None
+    if world == 1 and args.order == "reference" and args.dense_side_steps > 0 and not args.every_row:
+        model_a = None
+        try:
+            model_a = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2, row_begin=rb,
+                                 n_global=n, seed=seed, order="aggregate_first",
+                                 sparse_loss_gradient=not args.dense_loss_gradient)
+            model_a.train_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.dense_side_steps):
+                model_a.train_step()
+            torch.cuda.synchronize()
+            agg_ms = (time.perf_counter() - t1) / args.dense_side_steps * 1e3
+        except torch.cuda.OutOfMemoryError as exc:
+            print("[bench] aggregate-first side measurement skipped: %s" % (str(exc).splitlines()[0],), file=sys.stderr,
+                  flush=True)
+        finally:
+            model_a = None
+        torch.cuda.empty_cache()
+        note("aggregate-first side measurement done")
+
     if rank == 0:
         # work units: the nonzeros each SpMM multiplies (A_hat^T dZ: those of the labelled columns)
         model.field = field          # (the work of the timed steps)
@@ -607,10 +632,12 @@ def main():
             "ms_per_step_dense_gradients": dense_ms,
             "ms_per_step_f32_chains": f32_ms,
             "ms_per_step_f32_chains_dense_gradients": f32_dense_ms,
+            "ms_per_step_aggregate_first": agg_ms,
             "side_measurements": "after the timed region, a few steps each, not part of value: _every_row = every row of "
                                  "every activation formed, backward products over the rows and nonzeros that can be "
                                  "nonzero; _dense_gradients = every "
-                                 "product over every nonzero and row, as the reference multiplies; _f32_chains "
+                                 "product over every nonzero and row, as the reference multiplies; _aggregate_first = a second engine with --order aggregate_first ((A_hat X') W1: "
+                                 "one hidden-width SpMM per step instead of two, same result to rounding); _f32_chains "
                                  "= a second engine with every dense product on exact fp32 MFMA chains",
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,

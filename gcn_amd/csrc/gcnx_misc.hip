@@ -394,9 +394,9 @@ __global__ __launch_bounds__(kBlock) void pack_sign_bits_kernel(int64_t n_rows,
 // (row length `width`) the mask is defined on.  A thread handles 4 consecutive
 // columns (one Philox block) when vec_ok, else one element.
 __global__ __launch_bounds__(kBlock) void dropout_rows_philox_kernel(
-    int64_t n_rows, int32_t width, const float *__restrict__ x, int64_t ldx,
+    int64_t n_rows, int32_t width, const float *x, int64_t ldx,
     const int32_t *__restrict__ row_ids, float keep, float scale, uint64_t seed, uint64_t offset,
-    float *__restrict__ out, int64_t ldo, int vec_ok) {
+    float *out, int64_t ldo, int vec_ok) {   // out may be x (each element is read, then written, by one thread)
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (vec_ok) {

@@ -457,11 +457,16 @@ class FullBatchGCN(object):
         or None when it does not apply or would not pay."""
         k = self.k
         need = ("csr_transpose", "csr_keep_rows", "csr_compact_rows", "csr_filter_columns", "gather_rows")
-        if self.world != 1 or self.order != "reference" or self.at_dz_c is None or self.at_wide is None or \
-                self.keep_masks or any(not hasattr(k, n) for n in need):
+        agg = self.order == "aggregate_first"
+        if self.world != 1 or self.at_dz_c is None or self.keep_masks or any(not hasattr(k, n) for n in need):
             return
-        if self.keep <= 0.0:
+        if self.keep <= 0.0 or (agg and self.keep < 1.0 and not hasattr(k, "dropout_rows_philox")):
             return
+        at_wide = self.at_wide
+        if at_wide is None:
+            # (the aggregate-first order has no hidden-width backward product of its own)
+            rp = torch.as_tensor(self.at_dz.row_ptr)
+            at_wide = k.csr_filter_columns(self.at, (rp[1:] - rp[:-1]) > 0)
         dev, c, h = self.dev, self.c, self.h
         e = lambda *sh, **kw: torch.empty(sh, dtype=kw.get("dtype", torch.float32), device=dev)
         fd = type("LabelledField", (), {})()
@@ -479,19 +484,24 @@ class FullBatchGCN(object):
         if self.at_wide_c is not None:
             src, fd.rows2, fd.x2 = self.at_wide_c, self.hb_rows, self.x_c
         else:
-            sub, rows = k.csr_compact_rows(self.at_wide)
+            sub, rows = k.csr_compact_rows(at_wide)
             if 0 < int(sub.n_rows) <= (self.n_loc * 7) // 10 and (self.keep >= 1.0 or
                                                                   hasattr(k, "dropout_rows_philox")):
                 src, fd.rows2 = sub, rows.to(dev)
                 fd.x2 = torch.empty((int(sub.n_rows), self.f), dtype=torch.float32, device=dev)
                 k.gather_rows(self.x, fd.rows2, fd.x2)
             else:
-                src, fd.rows2, fd.x2 = self.at_wide, None, self.x
+                src, fd.rows2, fd.x2 = at_wide, None, self.x
         n2 = int(src.n_rows)
         # dropout(X) over N2: regenerated inside the two products that read it where their
         # shapes are served, else stored once per step
         fd.fuse_x = fd.xd = None
-        if self.keep < 1.0:
+        fd.agg = agg
+        if agg:
+            # (A_hat[N1, N2] X') W1: the sparse product reads dropout(X) over N2, stored once per step
+            if self.keep < 1.0:
+                fd.xd = e(n2, self.f) if fd.rows2 is not None or self.xd is None else self.xd
+        elif self.keep < 1.0:
             sup = getattr(k, "gemm_supports_a_dropout", None)
             sup_t = getattr(k, "gemm_supports_a_dropout_rows_t", None)
             fd.fuse_x = bool(sup is not None and sup(False, n2, h, self.f) and sup(True, self.f, h, n2) and
@@ -501,15 +511,21 @@ class FullBatchGCN(object):
         t = k.csr_transpose(src)                     # [n, n2]; only rows of N1 hold nonzeros
         fd.a_h = k.csr_keep_rows(t, fd.rows1)        # A_hat[N1, N2]
         del t
-        fd.a_ht = k.csr_transpose(fd.a_h)            # (A_hat^T)[N2, N1], columns numbered within N1
+        # (A_hat^T)[N2, N1], columns numbered within N1 (the aggregate-first order never forms dP1)
+        fd.a_ht = None if agg else k.csr_transpose(fd.a_h)
+        wide = self.f if agg else h                  # width of the operand the hidden-layer SpMM gathers
         hint = getattr(fd.a_h, "set_gather_hint", None)
-        if hint is not None and h > 128 and n2 * h * 4 > (1 << 30) and fd.a_h.nnz > (1 << 24):
-            hint(h * 4)
+        if hint is not None and wide > 128 and n2 * wide * 4 > (1 << 30) and fd.a_h.nnz > (1 << 24):
+            hint(wide * 4)
         fd.n_l, fd.n1, fd.n2 = n_l, n1, n2
         fd.nnz_h, fd.nnz_z = int(fd.a_h.nnz), int(fd.a_z.nnz)
-        fd.p1 = e(n2, h)                             # X' W1 over N2
-        # dP1 over N2
-        fd.hb = self.hb_c if self.at_wide_c is not None else self.hb if fd.rows2 is None else e(n2, h)
+        if agg:
+            fd.ax = e(n1, self.f)                    # A_hat[N1, N2] X'
+            fd.p1 = fd.hb = None
+        else:
+            fd.p1 = e(n2, h)                         # X' W1 over N2
+            # dP1 over N2
+            fd.hb = self.hb_c if self.at_wide_c is not None else self.hb if fd.rows2 is None else e(n2, h)
         fd.hd = self.hd_c                            # H' over N1
         fd.p2 = e(n1, c)
         fd.z, fd.dz = e(n_l, c), e(n_l, c)
@@ -530,6 +546,8 @@ class FullBatchGCN(object):
             if sup_bits is not None and sup_bits(h):
                 fd.hbits = torch.empty((n1, words), dtype=torch.int32, device=dev)
         fd.factored = bool(self.factored_bwd and fd.hbits is not None)
+        if agg:
+            fd.hbits = None                          # the gate is read from the few rows of H' themselves
         fd.g = None if fd.factored else e(n1, h)     # the gated product over N1 when it has to be stored
         self.field = fd
 
@@ -541,6 +559,8 @@ class FullBatchGCN(object):
         xkey = (keep, self.seed * 2 + 1, off + self.row_begin * self.f) if keep < 1.0 else None
         xrows = fd.rows2
         xin = fd.x2
+        if fd.agg:
+            return self._train_step_field_aggregate_first(xkey, off)
         if xkey is not None and not fd.fuse_x:
             if xrows is not None:
                 k.dropout_rows_philox(fd.x2, xrows, xkey[0], xkey[1], xkey[2], out=fd.xd)
@@ -574,6 +594,37 @@ class FullBatchGCN(object):
             k.gemm(xin, fd.hb, trans_a=True, out=self.g1, a_dropout=xkey, a_dropout_rows=xrows)
         else:
             k.gemm(xin, fd.hb, trans_a=True, out=self.g1)
+        k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)
+        k.adam_step(self.w2, self.g2, self.m2, self.v2, self.lr, self.step_no)
+        return out
+
+    def _train_step_field_aggregate_first(self, xkey, off):
+        """The step over the labelled rows' field with the first layer as
+        (A_hat[N1, N2] X') W1: the weight gradient is (A_hat[N1, N2] X')^T dZ1 with the
+        aggregate kept from the forward pass, so no product runs over N2 but the one
+        sparse product, and the dense ones run over the rows of N1."""
+        k, fd = self.k, self.field
+        keep = self.keep
+        xin = fd.x2
+        if xkey is not None:
+            if fd.rows2 is not None:
+                k.dropout_rows_philox(fd.x2, fd.rows2, xkey[0], xkey[1], xkey[2], out=fd.xd)
+            else:
+                k.dropout_philox(fd.x2.view(-1), xkey[0], xkey[1], xkey[2], out=fd.xd.view(-1))
+            xin = fd.xd
+        k.spmm(fd.a_h, xin, out=fd.ax)
+        k.gemm(fd.ax, self.w1, out=fd.hd, relu=True)
+        if keep < 1.0:
+            # H' = dropout(relu(.)), the mask of a row drawn by its node id
+            k.dropout_rows_philox(fd.hd, fd.rows1, keep, self.seed * 2 + 2, off + self.row_begin * self.h, out=fd.hd)
+        k.gemm(fd.hd, self.w2, out=fd.p2)
+        k.spmm(fd.a_z, fd.p2, out=fd.z)
+        out, _ = k.masked_softmax_xent(fd.z, fd.y, fd.ymask, want_grad=True, mask_total=self.mask_total,
+                                       grad_out=fd.dz)
+        k.spmm(fd.a_zt, fd.dz, out=fd.dp2)                                   # A^T dZ over N1
+        k.gemm(fd.hd, fd.dp2, trans_a=True, out=self.g2)                      # H'^T dP2
+        k.gemm(fd.dp2, self.w2, trans_b=True, out=fd.g, gate=fd.hd, gate_scale=1.0 / keep)
+        k.gemm(fd.ax, fd.g, trans_a=True, out=self.g1)                        # (A_hat X')^T dZ1
         k.adam_step(self.w1, self.g1, self.m1, self.v1, self.lr, self.step_no, weight_decay=self.wd)
         k.adam_step(self.w2, self.g2, self.m2, self.v2, self.lr, self.step_no)
         return out
@@ -973,6 +1024,8 @@ class FullBatchGCN(object):
         A step over the labelled rows' field multiplies the nonzeros of A_hat[N1, N2]
         twice at hidden width and those of A_hat[labelled, N1] twice at class width."""
         if self.field is not None:
+            if self.field.agg:
+                return self.field.nnz_h * self.f + 2 * self.field.nnz_z * self.c
             return 2 * (self.field.nnz_h * self.h + self.field.nnz_z * self.c)
         nz = nnz_global if nnz_loss_gradient_global is None else nnz_loss_gradient_global
         nb = nnz_global if nnz_backward_global is None else nnz_backward_global

@@ -571,8 +571,9 @@ int gcnx_dropout_philox_f32(int64_t n, const float *x, float keep, uint64_t seed
 
 /* The same dropout for a gathered subset of rows of a matrix with rows of
  * `width` elements: out[i][c] = keep(offset + row_ids[i] * width + c) ?
- * x[i][c] / keep : 0 (row i of x draws the mask of row row_ids[i]).  Used for
- * the resident copies of remote feature rows in the row-partitioned engine. */
+ * x[i][c] / keep : 0 (row i of x draws the mask of row row_ids[i]).  out may be
+ * x (in place).  Used for the resident copies of remote feature rows in the
+ * row-partitioned engine and for activations kept over a subset of the rows. */
 int gcnx_dropout_rows_philox_f32(int64_t n_rows, int32_t width, const float *x,
                                  int64_t ldx, const int32_t *row_ids, float keep,
                                  uint64_t seed, uint64_t offset, float *out,

@@ -323,6 +323,8 @@ def test_overlapped_and_blocking_class_exchange_agree(tmp_path):
     (32, 5, 0.5, 0.03, 8, False),       # sign words, bit-gated product then SpMM
     (64, 16, 0.5, 0.08, 8, False),      # N2 is most of the graph: X and dP1 keep their full height
     (64, 16, 0.5, 0.03, 8, True),       # a labelled node whose row of A_hat is empty: a zero row of logits
+    (64, 16, 0.5, 0.02, 9, "aggregate_first"),    # first layer as (A_hat[N1, N2] X') W1: no product over N2 but the SpMM
+    (16, 5, 0.0, 0.03, 8, "aggregate_first"), (64, 16, 0.5, 0.08, 8, "aggregate_first"),
     (64, 16, 0.5, 0.02, 9, "stored-dropout"),     # products that cannot regenerate dropout(X): stored over N2
     (64, 16, 0.5, 0.08, 8, "stored-dropout")])    # ... and over every row
 def test_labelled_field_step_matches_full_step(hidden, classes, dropout, label_rate, scale, no_self_loop):
@@ -334,6 +336,9 @@ def test_labelled_field_step_matches_full_step(hidden, classes, dropout, label_r
     n, a_hat, x, w1, w2, labels, lmask, hidden, classes = _problem(scale=scale, hidden=hidden, classes=classes,
                                                                    label_rate=label_rate)
     kernels = OracleKernels
+    order = "reference"
+    if no_self_loop == "aggregate_first":
+        order, no_self_loop = "aggregate_first", False
     if no_self_loop == "stored-dropout":
         no_self_loop = False
 
@@ -350,11 +355,14 @@ def test_labelled_field_step_matches_full_step(hidden, classes, dropout, label_r
     T = torch.from_numpy
     mk = lambda on: engine.FullBatchGCN(
         CpuCsr(a_hat), T(x.copy()), T(labels.copy()), T(lmask.copy()), int(lmask.sum()), hidden, classes, T(w1), T(w2),
-        seed=5, kernels=kernels(), dropout=dropout, labelled_field_only=on)
+        seed=5, kernels=kernels(), dropout=dropout, labelled_field_only=on, order=order)
     field, full = mk(True), mk(False)
     fd = field.field
     assert fd is not None and full.field is None
-    assert (fd.xd is not None) == (kernels is not OracleKernels) == (dropout > 0 and not fd.fuse_x)
+    if order == "aggregate_first":
+        assert fd.agg and fd.a_ht is None and (fd.xd is not None) == (dropout > 0)
+    else:
+        assert (fd.xd is not None) == (kernels is not OracleKernels) == (dropout > 0 and not fd.fuse_x)
     lab = np.nonzero(lmask)[0]
     n1_ref = np.unique(a_hat[lab].indices)                       # columns the labelled rows read
     n2_ref = np.unique(a_hat[n1_ref].indices)
@@ -366,7 +374,7 @@ def test_labelled_field_step_matches_full_step(hidden, classes, dropout, label_r
         assert fd.n2 == n and len(n2_ref) > (n * 7) // 10
     assert (fd.rows2 is None) == (label_rate >= 0.08)
     assert fd.nnz_h == a_hat[n1_ref].nnz and fd.nnz_z == a_hat[lab].nnz
-    assert fd.factored == (hidden == 64 and classes == 16)
+    assert fd.factored == (hidden == 64 and classes == 16 and order == "reference")
     if fd.factored:
         assert fd.dp2.stride(0) == 32 == fd.hbits.stride(0)
     for step in range(3):

@@ -76,7 +76,10 @@ def _dense_tuple(x):
     (256, 16, "reference-few-labels", 11, 128), (16, 7, "reference-few-labels", 10, 48),
     (128, 16, "aggregate_first-few-labels", 11, 64),
     # ... and the same with every row of every activation formed
-    (256, 16, "reference-few-labels-every-row", 11, 128), (16, 7, "reference-few-labels-every-row", 10, 48)])
+    (256, 16, "reference-few-labels-every-row", 11, 128), (16, 7, "reference-few-labels-every-row", 10, 48),
+    (128, 16, "aggregate_first-few-labels-every-row", 11, 64),
+    # the benchmark's widths in the other association over the field
+    (256, 16, "aggregate_first-few-labels", 12, 256)])
 def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
     from oracle import model as omodel
     torch, dev = env["torch"], env["dev"]
@@ -97,13 +100,15 @@ def test_engine_steps_match_oracle(env, hidden, classes, order, scale, f):
                                      T(w1), T(w2), seed=123, order=order, sparse_loss_gradient=sparse_dz,
                                      labelled_field_only=not every_row)
     lab_idx = np.nonzero(lmask)[0]
-    if every_row or order != "reference" or not sparse_dz:
+    if every_row or not sparse_dz:
         assert eng.field is None
     elif few:
         # the step over the labelled rows' field, its operand records as in the full-height step
         fd = eng.field
         assert fd is not None and np.array_equal(fd.lab_rows.cpu().numpy(), lab_idx) and fd.n1 < n // 2
-        assert fd.factored == (hidden == 256) and (not fd.factored or fd.dp2.stride(0) == 32 == fd.hbits.stride(0))
+        assert fd.agg == (order == "aggregate_first")
+        assert fd.factored == (hidden == 256 and not fd.agg)
+        assert not fd.factored or fd.dp2.stride(0) == 32 == fd.hbits.stride(0)
     if hidden == 256 and classes == 16 and order == "reference":
         # the operands of the factored backward product lie side by side, one 128-byte record per node
         assert eng.factored_bwd and eng.dp2.stride(0) == 32 == eng.hbits.stride(0)

@@ -853,6 +853,54 @@ def test_compact_rows_then_scatter_equals_the_full_product(env):
         assert torch.equal(out, full)
 
 
+@pytest.mark.parametrize("width", [16, 64, 256])
+def test_spmm_rows_subset_draws_masks_by_row_id(env, width):
+    """gcnx_spmm_csr_rows_f32: the product over a subset of the rows of a matrix,
+    stored next to each other (transpose -> column filter -> transpose -> keep_rows,
+    the way the engine builds A_hat[N1, :]), with relu + dropout drawn by the id of
+    each row and the sign words, equals the same rows of the full product: the kept /
+    dropped pattern and the sign words exactly, the values to rounding (the rows are
+    cut into partial sums at other places); a kept row that is empty stays a zero row."""
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    from gcn_amd.sparse import Csr
+    rng = np.random.RandomState(11)
+    n, n_cols = 3000, 2500
+    rows, cols, vals = random_coo(rng, n, n_cols, 60000, hub_rows=((5, 4000), (1700, 900)), empty_rows=(40, 41))
+    a = Csr.from_coo(rows, cols, vals.astype(np.float32), (n, n_cols), device=dev)
+    pick = np.unique(np.concatenate([[5, 40, 1700, n - 1], rng.choice(n, 700, replace=False)]))
+    flag = torch.zeros(n, dtype=torch.uint8, device=dev)
+    flag[torch.from_numpy(pick).to(dev)] = 1
+    ids = torch.from_numpy(pick.astype(np.int32)).to(dev)
+    sub = ops.csr_keep_rows(ops.csr_transpose(ops.csr_filter_columns(ops.csr_transpose(a), flag)), ids)
+    rp = a.row_ptr.cpu().numpy()
+    assert sub.n_rows == len(pick) and sub.nnz == int((rp[pick + 1] - rp[pick]).sum())
+    with pytest.raises(ValueError):
+        ops.csr_keep_rows(a, ids)                              # rows that hold nonzeros would be left out
+    b = torch.from_numpy(rng.standard_normal((n_cols, width)).astype(np.float32)).to(dev)
+    drop = (0.5, 77, 4 * 999, width, 0)
+    signs = width % 32 == 0
+    bits_f = torch.zeros((n, width // 32), dtype=torch.int32, device=dev) if signs else None
+    bits_s = torch.zeros((len(pick), width // 32), dtype=torch.int32, device=dev) if signs else None
+    full = ops.spmm(a, b, relu=True, dropout=drop, **({"sign_bits": bits_f} if signs else {}))
+    part = ops.spmm(sub, b, relu=True, dropout=drop, dropout_rows=ids, **({"sign_bits": bits_s} if signs else {}))
+    ref = full[ids.long()]
+    assert torch.equal(part != 0, ref != 0)
+    rp_, ci_, v_, _ = _csr_np(a)
+    _, mag = env["oracle"].spmm_csr_f64(rp_, ci_, v_, b.cpu().numpy())        # size of the summed terms per element
+    err = (part.double() - ref.double()).abs().cpu().numpy()
+    assert float((err / np.maximum(2.0 * mag[pick], 1e-30)).max()) <= RTOL
+    assert not part[int(np.searchsorted(pick, 40))].any()
+    if signs:
+        assert torch.equal(bits_s, bits_f[ids.long()])
+    # without row ids the same call draws the masks of rows 0, 1, 2, ...: another pattern
+    other = ops.spmm(sub, b, relu=True, dropout=drop)
+    assert not torch.equal(other != 0, ref != 0)
+    # no dropout: the row ids are not consulted and the rows are those of the plain product
+    plain = ops.spmm(sub, b, dropout_rows=ids)
+    err = (plain.double() - ops.spmm(a, b)[ids.long()].double()).abs().cpu().numpy()
+    assert float((err / np.maximum(mag[pick], 1e-30)).max()) <= RTOL
+
+
 @pytest.fixture(params=["split_bf16", "f32_chain"])
 def dense_arith(request, env):
     """Both arithmetic modes of the large dense products: exactly split operands
