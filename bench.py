@@ -260,10 +260,11 @@ def main():
                     help="several GPUs: form the class-width forward product in one piece behind a blocking halo "
                          "exchange (row sums in column order as on one GPU: results bitwise independent of the GPU "
                          "count); default: local columns during the exchange, halo columns after it")
-    ap.add_argument("--every-row", action="store_true",
-                    help="one GPU: form every row of every activation in the training step, as the reference does; "
-                         "default: only the rows the masked loss depends on (the labelled rows of Z, the rows of H' "
-                         "they read, the rows of P1 those read; same loss, accuracy and weight update)")
+    ap.add_argument("--labelled-field", action="store_true",
+                    help="one GPU: the timed training step forms only the rows the masked loss depends on (the "
+                         "labelled rows of Z, the rows of H' they read, the rows of P1 those read; same loss, accuracy "
+                         "and weight update).  Default: every row of every activation, as the reference's step forms "
+                         "them; the field step is then timed as a side measurement (ms_per_step_labelled_field)")
     ap.add_argument("--dense-loss-gradient", action="store_true",
                     help="form A_hat^T dZ over every nonzero, as the reference does; default: over the nonzeros of the "
                          "labelled columns only (the other rows of dZ are exactly zero; same result)")
@@ -397,7 +398,7 @@ def main():
                           slab_cols=args.slab_cols or None, halo_mode=args.halo_mode, order=args.order, comm=comm,
                           sparse_loss_gradient=not args.dense_loss_gradient,
                           overlap_class_exchange=not args.blocking_class_exchange,
-                          labelled_field_only=not args.every_row)
+                          labelled_field_only=args.labelled_field)
 
     model = make_engine()
     nnz_dz = torch.tensor([model.loss_gradient_nnz(), model.backward_nnz()], dtype=torch.int64,
@@ -491,22 +492,32 @@ def main():
     # Side measurement, outside the timed region and not part of `value`: the same
     # engine with every backward product over every nonzero and row (what
     # --dense-loss-gradient times as the main number), so that both forms come from one run.
-    dense_ms = every_row_ms = None
+    dense_ms = every_row_ms = field_ms = None
     field = model.field
-    field_info = None
-    if field is not None:
-        field_info = {"labelled_rows": field.n_l, "rows_of_H": field.n1, "rows_of_P1": field.n2,
-                      "nnz_hidden_width": field.nnz_h, "nnz_class_width": field.nnz_z}
-        if args.dense_side_steps > 0:
+    describe = lambda fd: {"labelled_rows": fd.n_l, "rows_of_H": fd.n1, "rows_of_P1": fd.n2,
+                           "nnz_hidden_width": fd.nnz_h, "nnz_class_width": fd.nnz_z}
+    field_info = describe(field) if field is not None else None
+    field_side = None
+
+    def side_steps(m):
+        m.train_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.dense_side_steps):
+            m.train_step()
+        barrier()
+        return (time.perf_counter() - t1) / args.dense_side_steps * 1e3
+
+    if args.dense_side_steps > 0:
+        if field is not None:
             # the same engine forming every row of every activation (backward shortcuts kept)
             model.field = None
-            model.train_step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.dense_side_steps):
-                model.train_step()
-            barrier()
-            every_row_ms = (time.perf_counter() - t1) / args.dense_side_steps * 1e3
+            every_row_ms = side_steps(model)
+        elif world == 1 and model.use_labelled_field():
+            # the same engine forming only the rows the masked loss depends on (an engine option)
+            field_side = describe(model.field)
+            field_ms = side_steps(model)
+            model.field = None
     if not args.dense_loss_gradient and model.at_dz is not None and args.dense_side_steps > 0:
         model.use_dense_gradients()
         model.train_step()
@@ -561,12 +572,12 @@ def main():
     # first layer associated the other way, (A_hat X') W1 -- an engine option whose results
     # agree with the reference's association to rounding, not to the bit.
     agg_ms = None
-    if world == 1 and args.order == "reference" and args.dense_side_steps > 0 and not args.every_row:
+    if world == 1 and args.order == "reference" and args.dense_side_steps > 0:
         model_a = None
         try:
             model_a = engine_cls(a, x, labels, lmask, mask_total, args.hidden, args.classes, w1, w2, row_begin=rb,
                                  n_global=n, seed=seed, order="aggregate_first",
-                                 sparse_loss_gradient=not args.dense_loss_gradient)
+                                 sparse_loss_gradient=not args.dense_loss_gradient, labelled_field_only=True)
             model_a.train_step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -609,10 +620,9 @@ def main():
                 "order": args.order, "dense_arith": args.dense_arith,
                 "nnz_loss_gradient_product": nnz_dz_global, "nnz_backward_product": nnz_bwd_global,
                 "gather_hint": bool(getattr(model.a if world == 1 else model.plan.csr, "gather_keep", None) is not None),
-                "rows_formed": ("every row of every activation" if field_info is None else
-                                "only what the masked loss reads: Z at the labelled rows, H' at the rows those read, "
-                                "P1 at the rows those read (same loss, accuracy and weight update; --every-row forms "
-                                "all rows)"),
+                "rows_formed": ("every row of every activation, as the reference's step forms them" if field_info is None
+                                else "only what the masked loss reads: Z at the labelled rows, H' at the rows those "
+                                     "read, P1 at the rows those read (same loss, accuracy and weight update)"),
                 "field": field_info,
                 "spmm_per_step": ("2 x width %d over the %d nonzeros of A_hat[rows of H', rows of P1] + 2 x width %d "
                                   "over the %d nonzeros of A_hat[labelled rows, rows of H'], counted as such in value"
@@ -629,15 +639,20 @@ def main():
             },
             "epoch_ms": dt / args.steps * 1e3,
             "ms_per_step_every_row": every_row_ms,
+            "ms_per_step_labelled_field": field_ms,
+            "labelled_field": field_side,
             "ms_per_step_dense_gradients": dense_ms,
             "ms_per_step_f32_chains": f32_ms,
             "ms_per_step_f32_chains_dense_gradients": f32_dense_ms,
-            "ms_per_step_aggregate_first": agg_ms,
-            "side_measurements": "after the timed region, a few steps each, not part of value: _every_row = every row of "
-                                 "every activation formed, backward products over the rows and nonzeros that can be "
-                                 "nonzero; _dense_gradients = every "
-                                 "product over every nonzero and row, as the reference multiplies; _aggregate_first = a second engine with --order aggregate_first ((A_hat X') W1: "
-                                 "one hidden-width SpMM per step instead of two, same result to rounding); _f32_chains "
+            "ms_per_step_labelled_field_aggregate_first": agg_ms,
+            "side_measurements": "after the timed region, a few steps each, not part of value: _dense_gradients = every "
+                                 "product over every nonzero and row, as the reference multiplies; _labelled_field = "
+                                 "the engine option that forms only the rows the masked loss reads (Z at the labelled "
+                                 "rows, H' at the rows those read, P1 at the rows those read: same loss, accuracy and "
+                                 "weights, `labelled_field` gives the row counts); _labelled_field_aggregate_first = "
+                                 "that option with the first layer as (A_hat X') W1 (one hidden-width SpMM, no product "
+                                 "over the rows of P1 but that one); _every_row = with --labelled-field, the step "
+                                 "that forms every row; _f32_chains "
                                  "= a second engine with every dense product on exact fp32 MFMA chains",
             "final_xent": loss_acc[0], "final_train_acc": loss_acc[1],
             "build_seconds": t_build,

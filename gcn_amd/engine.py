@@ -60,7 +60,7 @@ class FullBatchGCN(object):
                  dropout=0.5, seed=123, group=None, world_size=1, rank=0, slab_cols=None,
                  kernels=None, keep_masks=False, halo_mode="auto", order="reference", comm=None,
                  sparse_loss_gradient=True, overlap_class_exchange=True, pack_gate_operands=True,
-                 labelled_field_only=True):
+                 labelled_field_only=False):
         """``a_local``: Csr of the local rows of A_hat (global column ids);
         ``a_bwd_local``: local rows of A_hat^T (defaults to ``a_local``: the
         normalised adjacency of an undirected graph is bitwise symmetric).
@@ -91,8 +91,9 @@ class FullBatchGCN(object):
         instead of running in column order, so one rank and several agree to fp32
         rounding, not to the bit (False: one product after the exchange, bitwise
         independent of the rank count).
-        ``labelled_field_only`` (one rank, reference order, with
-        ``sparse_loss_gradient``): a training step forms only what its loss, its
+        ``labelled_field_only`` (opt-in; one rank, with ``sparse_loss_gradient``;
+        :meth:`use_labelled_field` switches an existing engine over): a training step
+        forms only what its loss, its
         accuracy and its weight update depend on.  The masked loss reads the logits
         of the labelled rows; those read H' at the nodes with a labelled neighbour
         (N1); those read P1 at the nodes with a neighbour in N1 (N2).  The step then
@@ -103,8 +104,10 @@ class FullBatchGCN(object):
         of the full computation (dropout masks are drawn by node id), so loss,
         accuracy and weights agree with it to the rounding of where a long row is cut
         into partial sums; the rows left out are the ones no output of the step
-        depends on.  ``evaluate()`` still forms every row.  False: every row of every
-        activation, as the reference does."""
+        depends on.  ``evaluate()`` still forms every row.  With ``order="aggregate_first"``
+        the field step forms (A_hat[N1, N2] X') W1: one sparse product over N2 and every
+        dense product over N1.  False (default): every row of every activation, as the
+        reference's step forms them."""
         self.k = kernels if kernels is not None else _hip_ops
         self.comm = comm
         self.a = a_local
@@ -227,6 +230,7 @@ class FullBatchGCN(object):
                 self.dp2_halo = self._gate_records_halo[:, :self.c]
                 self.hbits_halo = self._gate_records_halo.view(torch.int32)[:, self.c:self.c + words]
         self.field = None
+        self._pack_gate_operands = bool(pack_gate_operands)
         if labelled_field_only:
             self._setup_labelled_field(pack_gate_operands)
 
@@ -550,6 +554,13 @@ class FullBatchGCN(object):
             fd.hbits = None                          # the gate is read from the few rows of H' themselves
         fd.g = None if fd.factored else e(n1, h)     # the gated product over N1 when it has to be stored
         self.field = fd
+
+    def use_labelled_field(self):
+        """From now on the training step runs over the labelled rows' field (see
+        ``labelled_field_only``); returns whether it applies to this engine."""
+        if self.field is None:
+            self._setup_labelled_field(self._pack_gate_operands)
+        return self.field is not None
 
     def _train_step_field(self):
         """One optimisation step over the labelled rows' field (``self.field``)."""

@@ -312,8 +312,7 @@ def test_degree32_shard_at_scale(env):
     labels = torch.zeros((n, 16), device=dev)
     labels.scatter_(1, cls.view(-1, 1), 1.0)
     lmask = (torch.arange(n, device=dev) % 100 == 0).to(torch.uint8)
-    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123,
-                                     labelled_field_only=False)
+    eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123)
     assert eng.factored_bwd and eng.at_wide is not None and eng.at_wide.nnz < a.nnz
     w1_before = eng.w1.clone()
     out = eng.train_step().cpu().numpy()
@@ -345,6 +344,7 @@ def test_labelled_field_step_at_scale(env):
     labels.scatter_(1, cls.view(-1, 1), 1.0)
     lmask = (torch.arange(n, device=dev) % 100 == 0).to(torch.uint8)
     eng = env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask.sum().item()), 256, 16, w1, w2, seed=123)
+    assert eng.field is None and eng.use_labelled_field()        # opt-in; the engine is switched over after set-up
     fd = eng.field
     assert fd is not None and fd.factored and fd.dp2.stride(0) == 32 == fd.hbits.stride(0)
     # N1 = the columns the labelled rows hold, N2 = the columns the rows of N1 hold

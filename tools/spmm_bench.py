@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--hint", action="store_true", help="attach the cache hint of the wide kernel "
                     "(Csr.set_gather_hint at the first width's row size)")
     ap.add_argument("--hint-budget-mib", type=float, default=176.0, help="bytes of operand rows the hint keeps cacheable")
+    ap.add_argument("--field-of-labels", type=int, default=0, metavar="K",
+                    help="multiply A_hat[N1, N2] instead of A_hat: every K-th node labelled, N1 = the nodes a labelled "
+                         "row reads, N2 = the nodes a row of N1 reads, both stored next to each other (the matrix of "
+                         "the hidden-width forward product of the engine's step over the labelled rows' field)")
     ap.add_argument("--relabel", choices=["none", "degree"], default="none",
                     help="degree: renumber the vertices by descending degree first (hub rows of the operand "
                     "become neighbours in memory)")
@@ -39,6 +43,16 @@ def main():
         a = Csr.from_coo(new_id[rows].to(torch.int32), new_id[a.col_idx.long()].to(torch.int32), a.val,
                          (a.n_rows, a.n_cols), device=dev)
         del deg, order, new_id, rows
+    if args.field_of_labels:
+        lab = (torch.arange(a.n_rows, device=dev) % args.field_of_labels == 0)
+        at = a                                        # the normalised adjacency is bitwise symmetric
+        at_dz = ops.csr_filter_columns(at, lab)
+        hit = (at_dz.row_ptr[1:] - at_dz.row_ptr[:-1]) > 0
+        rows1 = torch.nonzero(hit).view(-1).to(torch.int32)
+        sub, rows2 = ops.csr_compact_rows(ops.csr_filter_columns(at, hit))
+        a = ops.csr_keep_rows(ops.csr_transpose(sub), rows1)
+        print("field: %d labelled, N1 %d rows, N2 %d rows" % (int(lab.sum()), rows1.numel(), rows2.numel()), flush=True)
+        del at, at_dz, hit, sub
     torch.cuda.synchronize()
     print("graph: n=%d nnz=%d max_deg=%d build %.2fs" % (
         a.n_rows, a.nnz, int((a.row_ptr[1:] - a.row_ptr[:-1]).max()), time.time() - t0), flush=True)
