@@ -224,6 +224,41 @@ int main() {
     if (!(apart <= 1e-6 * top)) return 1;
   }
 
+  // ---- output dropout drawn by row id (gcnx_spmm_csr_rows_f32) ------------------
+  {
+    std::vector<int32_t> ids((size_t)n_rows), rev((size_t)n_rows);
+    for (int64_t r2 = 0; r2 < n_rows; ++r2) {
+      ids[(size_t)r2] = (int32_t)r2;
+      rev[(size_t)r2] = (int32_t)(n_rows - 1 - r2);
+    }
+    int32_t *d_ids = dev_alloc<int32_t>(ids.size()), *d_rev = dev_alloc<int32_t>(rev.size());
+    float *d_o1 = dev_alloc<float>((size_t)n_rows * width), *d_o2 = dev_alloc<float>((size_t)n_rows * width);
+    float *d_o3 = dev_alloc<float>((size_t)n_rows * width);
+    if (!d_ids || !d_rev || !d_o1 || !d_o2 || !d_o3) return 2;
+    HIP_OK(hipMemcpy(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_rev, rev.data(), rev.size() * 4, hipMemcpyHostToDevice));
+    const gcnx_dropout drop = {0.5f, 99ull, 4ull * 1000ull, (int64_t)width, 0};
+    GCNX_OK_(gcnx_spmm_csr_split_f32(&a, d_chunk, d_b, width, nullptr, 0, n_cols, d_o1, width, width, 1.0f, 0.0f, nullptr,
+                                     nullptr, 1.0f, 1, &drop, sp_ws, sp_bytes, stream));
+    GCNX_OK_(gcnx_spmm_csr_rows_f32(&a, d_chunk, d_b, width, nullptr, 0, n_cols, d_o2, width, width, 1.0f, 0.0f, 1, &drop,
+                                    d_ids, nullptr, 0, sp_ws, sp_bytes, stream));
+    GCNX_OK_(gcnx_spmm_csr_rows_f32(&a, d_chunk, d_b, width, nullptr, 0, n_cols, d_o3, width, width, 1.0f, 0.0f, 1, &drop,
+                                    d_rev, nullptr, 0, sp_ws, sp_bytes, stream));
+    std::vector<float> o1((size_t)n_rows * width), o2(o1.size()), o3(o1.size());
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(o1.data(), d_o1, o1.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(o2.data(), d_o2, o2.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(o3.data(), d_o3, o3.size() * 4, hipMemcpyDeviceToHost));
+    size_t differ = 0;
+    for (size_t i = 0; i < o1.size(); ++i) {
+      if (std::memcmp(&o1[i], &o2[i], 4) != 0) return 1;      // row r drawing the mask of row r: the plain epilogue
+      differ += (o1[i] != 0.0f) != (o3[i] != 0.0f);
+    }
+    std::printf("dropout by row id: identity ids reproduce the plain epilogue; reversed ids change %zu of %zu elements\n",
+                differ, o1.size());
+    if (differ == 0) return 1;
+  }
+
   // ---- dense product ---------------------------------------------------------
   std::vector<float> ha((size_t)M * K), hb((size_t)K * N), hc((size_t)M * N);
   for (auto &v : ha) v = (float)urand();
