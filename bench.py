@@ -203,6 +203,7 @@ def one_gpu_denominator(args, shard_scale):
             continue
         cfg = rec.get("config", {}) if isinstance(rec, dict) else {}
         if rec.get("n_gpus") == 1 and str(cfg.get("workload", "")).startswith(want) and \
+                cfg.get("field") is None and "profiled_run" not in name and \
                 cfg.get("order", "reference") == args.order and \
                 cfg.get("dense_arith", "f32") == args.dense_arith and rec.get("value"):
             out["recorded"] = {"file": "profiles/" + name, "value": rec["value"], "unit": rec.get("unit"),
