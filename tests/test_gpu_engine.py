@@ -327,6 +327,59 @@ def test_degree32_shard_at_scale(env):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("hidden,classes,f,dropout,order,scale,rate", [
+    (64, 16, 32, 0.5, "reference", 12, 0.01), (64, 16, 32, 0.0, "reference", 12, 0.01),
+    (128, 7, 48, 0.5, "reference", 12, 0.02), (32, 5, 20, 0.5, "reference", 11, 0.02),
+    (16, 3, 12, 0.3, "reference", 11, 0.02), (256, 16, 256, 0.5, "reference", 14, 0.005),
+    (64, 16, 32, 0.5, "aggregate_first", 12, 0.01), (128, 7, 48, 0.0, "aggregate_first", 12, 0.02),
+    (256, 16, 256, 0.5, "aggregate_first", 14, 0.005)])
+def test_labelled_field_matches_every_row(env, hidden, classes, f, dropout, order, scale, rate):
+    """Two engines from the same weights, one stepping over the labelled rows' field,
+    one forming every row: three steps with the same losses, accuracies, gradients and
+    weights to rounding, whatever kernels the widths select (sign words or not,
+    factored backward product or gated product + SpMM, fused or stored dropout)."""
+    torch, dev = env["torch"], env["dev"]
+    n = 1 << scale
+    a = env["rmat"].rmat_ahat(scale, 8, 321, dev)
+    rng = np.random.RandomState(scale + hidden)
+    T = lambda v: torch.from_numpy(v).to(dev)
+    x = T(rng.uniform(-1, 1, (n, f)).astype(np.float32))
+    w1 = T((rng.uniform(-1, 1, (f, hidden)) * 0.2).astype(np.float32))
+    w2 = T((rng.uniform(-1, 1, (hidden, classes)) * 0.2).astype(np.float32))
+    labels = T(np.eye(classes, dtype=np.float32)[rng.randint(0, classes, n)])
+    lmask_h = (rng.random_sample(n) < rate).astype(np.uint8)
+    lmask = T(lmask_h)
+    mk = lambda on: env["engine"].FullBatchGCN(a, x, labels, lmask, int(lmask_h.sum()), hidden, classes, w1, w2,
+                                               seed=9, order=order, dropout=dropout, labelled_field_only=on)
+    field, full = mk(True), mk(False)
+    fd = field.field
+    assert fd is not None and full.field is None and fd.agg == (order == "aggregate_first")
+    assert fd.n_l == int(lmask_h.sum()) and fd.n1 <= n // 2
+    lab = torch.nonzero(lmask).view(-1)
+    lr, wd = 0.01, 5e-4
+    slack = {"w1": 0.0, "w2": 0.0}
+    for step in range(3):
+        w1_before = full.w1.clone()
+        o1, o2 = field.train_step().cpu().numpy(), full.train_step().cpu().numpy()
+        assert abs(o1[0] - o2[0]) <= 1e-5 * abs(o2[0]) + 1e-7 and abs(o1[1] - o2[1]) <= 1e-6, (step, o1, o2)
+        for name in ("g1", "g2"):
+            ref = getattr(full, name)
+            assert float((getattr(field, name) - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (name, step)
+        # Adam divides a gradient by its own size: an element whose gradient entered
+        # relatively off by e moves off by up to ~2 lr min(1, e) in this and each later
+        # step (only elements whose gradient is within rounding of zero get any room)
+        for name, gname, decay in (("w1", "g1", wd * w1_before), ("w2", "g2", 0.0)):
+            g_ref = getattr(full, gname) + decay
+            e = ((getattr(field, gname) - getattr(full, gname)).abs() / (g_ref.abs() + 1e-30)).clamp(max=1.0)
+            slack[name] = slack[name] + 2.0 * lr * e * (3 - step)
+            err = (getattr(field, name) - getattr(full, name)).abs()
+            assert bool((err <= 2e-6 * (step + 1) + slack[name]).all()), (name, step, float(err.max()))
+            assert float(torch.quantile(slack[name].flatten()[:1 << 20], 0.9)) <= 0.05 * lr
+        assert float((fd.z - full.z[lab]).abs().max()) <= 1e-5 * float(full.z.abs().max())
+    e1, e2 = field.evaluate().cpu().numpy(), full.evaluate().cpu().numpy()
+    assert abs(e1[0] - e2[0]) <= 1e-5 * abs(e2[0]) + 1e-7
+
+
 def test_labelled_field_step_at_scale(env):
     """The benchmark's graph and widths (RMAT 2^24, degree 16, 1 % labelled): the
     training step over the labelled rows' field against the step that forms every
